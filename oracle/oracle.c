@@ -1,0 +1,448 @@
+/* oracle.c — CPU restatement of the reference's box-geometry hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this; the product (vision_amd/) never does.
+ *
+ * Plain C, scalar, single-threaded, compiled with -O2 -ffp-contract=off so every
+ * float op is one IEEE-754 operation in the order the reference's torch/numpy
+ * expression evaluates it.  Each function cites the reference lines it follows
+ * (paths relative to the reference repo).  Pinned against tests/golden/*.npz,
+ * which were produced by executing the reference's own function bodies
+ * (oracle/gen_golden.py).  The 1-IoU k-means has NO reference counterpart
+ * ("parity unpinned"): its spec is stated at orc_kmeans_*.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORC_OK 0
+#define ORC_EINVAL (-1)
+#define ORC_EEMPTYROI (-2)
+#define ORC_EASSERT (-3)
+
+/* torch.max / torch.min (elementwise, two tensors) propagate NaN. */
+static inline float tmaxf(float a, float b) { return (a != a || b != b) ? NAN : (a > b ? a : b); }
+static inline float tminf(float a, float b) { return (a != a || b != b) ? NAN : (a < b ? a : b); }
+static inline double tmaxd(double a, double b) { return (a != a || b != b) ? NAN : (a > b ? a : b); }
+static inline double tmind(double a, double b) { return (a != a || b != b) ? NAN : (a < b ? a : b); }
+
+/* ---- I1 / I2: yolo/yolo_v1/modules.py:73-98 (eps 1e-7), :208-228 (eps 1e-6);
+ *      byte-identical copy yolo/yolo_v2/utils.py:238-263 ------------------------- */
+static inline float iou1_f32(const float *p, const float *q, float eps)
+{
+    float x_left = tmaxf(p[0], q[0]);            /* :84 */
+    float y_top = tmaxf(p[1], q[1]);             /* :85 */
+    float x_right = tminf(p[2], q[2]);           /* :86 */
+    float y_bottom = tminf(p[3], q[3]);          /* :87 */
+    float ix = x_right - x_left;                 /* :89 */
+    float iy = y_bottom - y_top;                 /* :90 */
+    if (ix < 0) ix = 0;                          /* :91 masked assign; NaN stays */
+    if (iy < 0) iy = 0;                          /* :92 */
+    float inter = ix * iy;                       /* :94 */
+    float a1 = fabsf((p[2] - p[0]) * (p[3] - p[1]));   /* :95 */
+    float a2 = fabsf((q[2] - q[0]) * (q[3] - q[1]));   /* :96 */
+    return inter / (((a1 + a2) - inter) + eps);  /* :97, left-to-right */
+}
+
+void orc_iou_elementwise_f32(const float *bb1, const float *bb2, int64_t n, float eps, float *out)
+{
+    for (int64_t i = 0; i < n; ++i) out[i] = iou1_f32(bb1 + 4 * i, bb2 + 4 * i, eps);
+}
+
+/* same expression when the caller passes float64 tensors (dtype follows the input) */
+void orc_iou_elementwise_f64(const double *bb1, const double *bb2, int64_t n, double eps, double *out)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        const double *p = bb1 + 4 * i, *q = bb2 + 4 * i;
+        double ix = tmind(p[2], q[2]) - tmaxd(p[0], q[0]);
+        double iy = tmind(p[3], q[3]) - tmaxd(p[1], q[1]);
+        if (ix < 0) ix = 0;
+        if (iy < 0) iy = 0;
+        double inter = ix * iy;
+        double a1 = fabs((p[2] - p[0]) * (p[3] - p[1]));
+        double a2 = fabs((q[2] - q[0]) * (q[3] - q[1]));
+        out[i] = inter / (((a1 + a2) - inter) + eps);
+    }
+}
+
+/* N x M matrix of I1 (never materialised by the reference; row i is what
+ * yolo/yolo_v1/yolo.py:200 computes with expand_as for head box i). */
+void orc_iou_pairwise_f32(const float *a, int64_t n, const float *b, int64_t m, float eps, float *out)
+{
+    for (int64_t i = 0; i < n; ++i)
+        for (int64_t j = 0; j < m; ++j) out[i * m + j] = iou1_f32(a + 4 * i, b + 4 * j, eps);
+}
+
+/* ---- I3: rcnn/utils.py:50-67 (dup rcnn/fast_rcnn.py:62-79), float64, asserts ----- */
+int orc_iou_scalar_f64(const double *bb1, const double *bb2, double *out)
+{
+    if (!(bb1[0] < bb1[2]) || !(bb1[1] < bb1[3]) || !(bb2[0] < bb2[2]) || !(bb2[1] < bb2[3]))
+        return ORC_EASSERT;                                    /* :51-54 */
+    double x_left = bb1[0] > bb2[0] ? bb1[0] : bb2[0];         /* python max */
+    double y_top = bb1[1] > bb2[1] ? bb1[1] : bb2[1];
+    double x_right = bb1[2] < bb2[2] ? bb1[2] : bb2[2];
+    double y_bottom = bb1[3] < bb2[3] ? bb1[3] : bb2[3];
+    if (x_right < x_left || y_bottom < y_top) { *out = 0.0; return ORC_OK; }  /* :59-60 */
+    double inter = (x_right - x_left) * (y_bottom - y_top);    /* :61 */
+    double a1 = (bb1[2] - bb1[0]) * (bb1[3] - bb1[1]);
+    double a2 = (bb2[2] - bb2[0]) * (bb2[3] - bb2[1]);
+    double iou = inter / ((a1 + a2) - inter);                  /* :64, no eps */
+    if (!(iou >= 0.0) || !(iou <= 1.0)) return ORC_EASSERT;    /* :65-66 */
+    *out = iou;
+    return ORC_OK;
+}
+
+/* ---- N1: yolo/yolo_v1/yolo.py:188-203 -------------------------------------------
+ * Literal restatement: sort ids by score descending, then
+ *   while numel(ids) > 1: pop head -> keep; ids = ids[iou(head, ids) < thr]
+ * The candidate left alone at the end is NOT kept (the numel()>1 quirk).
+ * torch casts the python threshold to fp32 for the compare (verified in
+ * gen_golden.py's probe), and NaN < thr is false (suppressed).
+ * Sort: descending score, ties by ascending index (the reference sort is
+ * unstable, so only tie-free inputs are comparable). */
+typedef struct { float s; int64_t i; } orc_si;
+static int cmp_desc(const void *a, const void *b)
+{
+    const orc_si *x = a, *y = b;
+    if (x->s > y->s) return -1;
+    if (x->s < y->s) return 1;
+    return (x->i > y->i) - (x->i < y->i);
+}
+
+int orc_nms_f32(const float *boxes, const float *scores, int64_t n, double threshold,
+                int quirk_drop_last, int64_t *keep, int64_t *n_keep)
+{
+    *n_keep = 0;
+    if (n <= 0) return ORC_OK;                                  /* :189,203 */
+    float thr = (float)threshold;
+    orc_si *ord = malloc(sizeof(orc_si) * (size_t)n);
+    int64_t *ids = malloc(sizeof(int64_t) * (size_t)n);
+    if (!ord || !ids) { free(ord); free(ids); return ORC_EINVAL; }
+    for (int64_t i = 0; i < n; ++i) { ord[i].s = scores[i]; ord[i].i = i; }
+    qsort(ord, (size_t)n, sizeof(orc_si), cmp_desc);            /* :194 */
+    for (int64_t i = 0; i < n; ++i) ids[i] = ord[i].i;
+    int64_t cnt = n, k = 0;
+    int64_t *cur = ids;
+    while (cnt > (quirk_drop_last ? 1 : 0)) {                   /* :196 */
+        int64_t head = cur[0];                                  /* :197 */
+        keep[k++] = head;                                       /* :198 */
+        cur += 1; cnt -= 1;                                     /* :199 */
+        int64_t w = 0;
+        for (int64_t j = 0; j < cnt; ++j) {                     /* :200-201 */
+            float iou = iou1_f32(boxes + 4 * head, boxes + 4 * cur[j], 1e-7f);
+            if (iou < thr) cur[w++] = cur[j];
+        }
+        cnt = w;
+    }
+    *n_keep = k;
+    free(ord); free(ids);
+    return ORC_OK;
+}
+
+/* ---- D1: yolo/yolo_v1/yolo.py:115-186, one image ----------------------------------
+ * output/target: (7,7,10+C) fp32.  Boxes are computed in float64 (fp32 tensor +
+ * float64 numpy grid promotes, :137) and rounded to fp32 once (:180).
+ * Output order: slot-1 hits in row-major cell order, then slot-2 hits (:164-178).
+ * Returns the number of candidates M (0 => the reference returns empty lists). */
+int64_t orc_yolo1_decode(const float *output, const float *target, int64_t C,
+                         double conf_threshold, double prob_threshold,
+                         float *out_box, int64_t *out_label, float *out_conf, float *out_score,
+                         double *bbox_target, int64_t *label_target)
+{
+    const int S = 7;
+    const int64_t N = 10 + C;
+    const float ct = (float)conf_threshold, pt = (float)prob_threshold;
+    int64_t m = 0;
+    for (int slot = 0; slot < 2; ++slot) {
+        for (int cy = 0; cy < S; ++cy)
+            for (int cx = 0; cx < S; ++cx) {
+                const float *o = output + ((int64_t)cy * S + cx) * N;
+                /* :124 torch.max over the class channels: value and index of the max.
+                 * (first maximal index; NaN would win — not exercised) */
+                float cs = o[10]; int64_t cl = 0;
+                for (int64_t c = 1; c < C; ++c) if (o[10 + c] > cs) { cs = o[10 + c]; cl = c; }
+                float conf = o[4 + 5 * slot];                     /* :125 */
+                float prob = conf * cs;                           /* :126 fp32 */
+                if (!((prob >= pt) && (cs > ct))) continue;       /* :161-162 */
+                const float *bx = o + 5 * slot;
+                /* :129-131 lt_norm = cell * 1 / 7 in float64 (numpy int*1/7) */
+                double ltx = (double)(cx * 1) / 7.0, lty = (double)(cy * 1) / 7.0;
+                /* :137  boxes * 1 / 7 : fp32 tensor ops, then + float64 */
+                double x = (double)((bx[0] * 1.0f) / 7.0f) + ltx;
+                double y = (double)((bx[1] * 1.0f) / 7.0f) + lty;
+                double hw = (double)(bx[2] / 2.0f), hh = (double)(bx[3] / 2.0f);   /* :144 wh/2 in fp32 */
+                out_box[4 * m + 0] = (float)(x - hw);             /* :144, :180 */
+                out_box[4 * m + 1] = (float)(y - hh);
+                out_box[4 * m + 2] = (float)(x + hw);             /* :145 */
+                out_box[4 * m + 3] = (float)(y + hh);
+                out_label[m] = cl; out_conf[m] = conf; out_score[m] = cs;
+                ++m;
+            }
+    }
+    if (target) {
+        /* :121 point_ind = target.sum(-1) != 0 ; the reference assumes one such cell */
+        for (int cy = 0; cy < S; ++cy)
+            for (int cx = 0; cx < S; ++cx) {
+                const float *t = target + ((int64_t)cy * S + cx) * N;
+                float sum = 0.f;
+                for (int64_t c = 0; c < N; ++c) sum += t[c];
+                if (sum == 0.f) continue;
+                /* :134 argsort(target[10:])[-1] + 1 : index of the largest class entry, 1-based */
+                int64_t best = 0;
+                for (int64_t c = 1; c < C; ++c) if (t[10 + c] >= t[10 + best]) best = c;
+                *label_target = best + 1;
+                double ltx = (double)(cx * 1) / 7.0, lty = (double)(cy * 1) / 7.0;
+                double x = (double)((t[0] * 1.0f) / 7.0f) + ltx;  /* :140 */
+                double y = (double)((t[1] * 1.0f) / 7.0f) + lty;
+                double hw = (double)(t[2] / 2.0f), hh = (double)(t[3] / 2.0f);     /* :146 */
+                bbox_target[0] = x - hw; bbox_target[1] = y - hh;
+                bbox_target[2] = x + hw; bbox_target[3] = y + hh;  /* :152 float64 */
+                return m;
+            }
+    }
+    return m;
+}
+
+/* ---- R1: rcnn/fast_rcnn.py:351-377 --------------------------------------------------
+ * roi window: x1=floor(x1*W) x2=ceil(x2*W) y1=floor(y1*H) y2=ceil(y2*H) in float64 (:366-369)
+ * then torch adaptive pooling of the crop to PxP: bin i over length L is
+ * [floor(i*L/P), ceil((i+1)*L/P)) (ATen, not in the reference tree).
+ * mode 0 = AdaptiveAvgPool2d (as written, :354), mode 1 = AdaptiveMaxPool2d with
+ * argmax (north_star).  ATen max: first maximum in row-major scan, NaN wins.
+ * argmax is the flat index y*W+x in the feature-map plane (build-defined). */
+static inline int bin_start(int i, int L, int P) { return (i * L) / P; }
+static inline int bin_end(int i, int L, int P) { return ((i + 1) * L + P - 1) / P; }
+
+int orc_roi_window(const double *roi, int H, int W, int *x1, int *y1, int *x2, int *y2)
+{
+    *x1 = (int)floor(roi[0] * (double)W);
+    *x2 = (int)ceil(roi[2] * (double)W);
+    *y1 = (int)floor(roi[1] * (double)H);
+    *y2 = (int)ceil(roi[3] * (double)H);
+    /* python slicing clamps; an empty crop makes torch raise */
+    if (*x1 < 0) *x1 = (*x1 + W < 0) ? 0 : *x1 + W;   /* negative python index wraps */
+    if (*y1 < 0) *y1 = (*y1 + H < 0) ? 0 : *y1 + H;
+    if (*x2 > W) *x2 = W;
+    if (*y2 > H) *y2 = H;
+    if (*x2 <= *x1 || *y2 <= *y1) return ORC_EEMPTYROI;
+    return ORC_OK;
+}
+
+int orc_roipool_fwd_f32(const float *img, int64_t B, int64_t C, int H, int W,
+                        const double *rois, const int64_t *roi_idx, int64_t n, int P, int mode,
+                        float *out, int32_t *argmax)
+{
+    for (int64_t r = 0; r < n; ++r) {
+        int x1, y1, x2, y2;
+        int st = orc_roi_window(rois + 4 * r, H, W, &x1, &y1, &x2, &y2);
+        if (st) return st;
+        int64_t b = roi_idx[r];
+        if (b < 0 || b >= B) return ORC_EINVAL;
+        int Lh = y2 - y1, Lw = x2 - x1;
+        for (int64_t c = 0; c < C; ++c) {
+            const float *plane = img + (b * C + c) * (int64_t)H * W;
+            for (int ph = 0; ph < P; ++ph) {
+                int hs = y1 + bin_start(ph, Lh, P), he = y1 + bin_end(ph, Lh, P);
+                for (int pw = 0; pw < P; ++pw) {
+                    int ws = x1 + bin_start(pw, Lw, P), we = x1 + bin_end(pw, Lw, P);
+                    int64_t o = ((r * C + c) * P + ph) * P + pw;
+                    if (mode == 1) {
+                        float best = -INFINITY; int32_t bi = hs * W + ws;
+                        for (int y = hs; y < he; ++y)
+                            for (int x = ws; x < we; ++x) {
+                                float v = plane[y * W + x];
+                                if ((v > best) || (v != v)) { best = v; bi = y * W + x; }
+                            }
+                        out[o] = best;
+                        if (argmax) argmax[o] = bi;
+                    } else {
+                        float sum = 0.f;
+                        for (int y = hs; y < he; ++y)
+                            for (int x = ws; x < we; ++x) sum += plane[y * W + x];
+                        out[o] = sum / (float)(he - hs) / (float)(we - ws);
+                    }
+                }
+            }
+        }
+    }
+    return ORC_OK;
+}
+
+/* ---- R2: backward of R1 (autograd in the reference; no explicit code).
+ * max: grad_in[b,c,argmax] += grad_out ; avg: grad_out / kh / kw spread over the bin.
+ * Sequential accumulation in RoI order (fp32). grad_in must be zeroed by the caller. */
+int orc_roipool_bwd_f32(const float *grad_out, const int32_t *argmax, int64_t B, int64_t C, int H, int W,
+                        const double *rois, const int64_t *roi_idx, int64_t n, int P, int mode,
+                        float *grad_in)
+{
+    for (int64_t r = 0; r < n; ++r) {
+        int x1, y1, x2, y2;
+        int st = orc_roi_window(rois + 4 * r, H, W, &x1, &y1, &x2, &y2);
+        if (st) return st;
+        int64_t b = roi_idx[r];
+        int Lh = y2 - y1, Lw = x2 - x1;
+        for (int64_t c = 0; c < C; ++c) {
+            float *plane = grad_in + (b * C + c) * (int64_t)H * W;
+            for (int ph = 0; ph < P; ++ph)
+                for (int pw = 0; pw < P; ++pw) {
+                    int64_t o = ((r * C + c) * P + ph) * P + pw;
+                    if (mode == 1) {
+                        plane[argmax[o]] += grad_out[o];
+                    } else {
+                        int hs = y1 + bin_start(ph, Lh, P), he = y1 + bin_end(ph, Lh, P);
+                        int ws = x1 + bin_start(pw, Lw, P), we = x1 + bin_end(pw, Lw, P);
+                        float g = grad_out[o] / (float)(he - hs) / (float)(we - ws);
+                        for (int y = hs; y < he; ++y)
+                            for (int x = ws; x < we; ++x) plane[y * W + x] += g;
+                    }
+                }
+        }
+    }
+    return ORC_OK;
+}
+
+/* ---- D3: yolo/yolo_v2/utils.py:228-234 get_point (encoder) and its inverse ---------
+ * center = xy + wh/2 ; points = (center // (1/13)).long() ; normed = (center % (1/13)) / (1/13)
+ * all in fp32 torch arithmetic; 1/13 is a python double cast to fp32 by torch.
+ * torch floor_divide / remainder on floats: remainder(a,b) = a - b*floor(a/b);
+ * floor_divide uses the fmod-based "div_floor" form. */
+static float t_remainder(float a, float b)
+{
+    float m = fmodf(a, b);
+    if (m != 0.f && ((b < 0.f) != (m < 0.f))) m += b;
+    return m;
+}
+static float t_floordiv(float a, float b)
+{
+    float m = fmodf(a, b);
+    float d = (a - m) / b;
+    if (m != 0.f && ((b < 0.f) != (m < 0.f))) d -= 1.f;
+    float f;
+    if (d != 0.f) { f = floorf(d); if (d - f > 0.5f) f += 1.f; }
+    else f = copysignf(0.f, a / b);
+    return f;
+}
+void orc_yolo2_get_point(const float *bbox, int64_t n, int64_t *points, float *enc)
+{
+    const float cell = (float)(1.0 / 13.0);
+    for (int64_t i = 0; i < n; ++i) {
+        const float *b = bbox + 4 * i;
+        for (int d = 0; d < 2; ++d) {
+            float center = b[d] + b[2 + d] / 2.0f;                 /* :229 */
+            points[2 * i + d] = (int64_t)t_floordiv(center, cell); /* :231 */
+            float residual = t_remainder(center, cell);            /* :232 */
+            enc[4 * i + d] = residual / cell;                      /* :233 */
+            enc[4 * i + 2 + d] = b[2 + d];                         /* :234 */
+        }
+    }
+}
+/* Inverse (build-defined; the reference has no YOLOv2 decode):
+ * center = (points + normed)/13 ; xyxy = center -/+ wh/2, fp32. */
+void orc_yolo2_decode_cells(const int64_t *points, const float *enc, int64_t n, float *xyxy)
+{
+    for (int64_t i = 0; i < n; ++i)
+        for (int d = 0; d < 2; ++d) {
+            float center = ((float)points[2 * i + d] + enc[4 * i + d]) / 13.0f;
+            float half = enc[4 * i + 2 + d] / 2.0f;
+            xyxy[4 * i + d] = center - half;
+            xyxy[4 * i + 2 + d] = center + half;
+        }
+}
+/* Standard anchor form (Redmon & Farhadi 2016, eq. in §2 "Direct location prediction"):
+ * bx = (sigmoid(tx)+cx)/G, by likewise, bw = pw*exp(tw), bh = ph*exp(th); conf = sigmoid(to).
+ * pred: (G,G,A,5+C) fp32, anchors (A,2) in grid-normalised units (fraction of image).
+ * Parity unpinned (no reference code); computed in double, rounded once. */
+void orc_yolo2_decode_anchor(const float *pred, int64_t G, int64_t A, int64_t C, const float *anchors,
+                             float *xyxy, float *conf)
+{
+    int64_t N = 5 + C;
+    for (int64_t gy = 0; gy < G; ++gy)
+        for (int64_t gx = 0; gx < G; ++gx)
+            for (int64_t a = 0; a < A; ++a) {
+                int64_t k = (gy * G + gx) * A + a;
+                const float *p = pred + k * N;
+                double sx = 1.0 / (1.0 + exp(-(double)p[0])), sy = 1.0 / (1.0 + exp(-(double)p[1]));
+                double bx = (sx + (double)gx) / (double)G, by = (sy + (double)gy) / (double)G;
+                double bw = (double)anchors[2 * a] * exp((double)p[2]);
+                double bh = (double)anchors[2 * a + 1] * exp((double)p[3]);
+                xyxy[4 * k + 0] = (float)(bx - bw / 2); xyxy[4 * k + 1] = (float)(by - bh / 2);
+                xyxy[4 * k + 2] = (float)(bx + bw / 2); xyxy[4 * k + 3] = (float)(by + bh / 2);
+                conf[k] = (float)(1.0 / (1.0 + exp(-(double)p[4])));
+            }
+}
+
+/* ---- next(2): rcnn/utils.py:153-171 calcul, and its inverse rcnn/rcnn.py:287-310 -- */
+void orc_rcnn_calcul_f32(const float *positive, int64_t n, const float *grt, float *t)
+{
+    float g_w = grt[2] - grt[0], g_h = grt[3] - grt[1];
+    float g_x = grt[0] + g_w / 2, g_y = grt[1] + g_h / 2;
+    for (int64_t i = 0; i < n; ++i) {
+        const float *p = positive + 4 * i;
+        float p_w = p[2] - p[0], p_h = p[3] - p[1];
+        float p_x = p[0] + p_w / 2, p_y = p[1] + p_h / 2;
+        t[4 * i + 0] = (g_x - p_x) / p_w;
+        t[4 * i + 1] = (g_y - p_y) / p_h;
+        t[4 * i + 2] = logf(g_w / p_w);
+        t[4 * i + 3] = logf(g_h / p_h);
+    }
+}
+/* variant 0: rcnn/rcnn.py:292-310 (px = xmin + pw/2, int rects: pw/2 is true division -> fp32)
+ * variant 1: rcnn/fast_rcnn.py:543-560 (px = (xmax + xmin)/2) */
+void orc_rcnn_decode_f32(const int32_t *p_rect, const float *tset, int64_t n, int variant, float *g)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        const int32_t *p = p_rect + 4 * i; const float *t = tset + 4 * i;
+        float pw = (float)(p[2] - p[0]), ph = (float)(p[3] - p[1]);
+        float px, py;
+        if (variant == 0) { px = (float)p[0] + pw / 2; py = (float)p[1] + ph / 2; }
+        else { px = (float)(p[2] + p[0]) / 2; py = (float)(p[3] + p[1]) / 2; }
+        float gx = pw * t[0] + px, gy = ph * t[1] + py;
+        float gw = pw * expf(t[2]), gh = ph * expf(t[3]);
+        g[4 * i + 0] = gx - gw / 2; g[4 * i + 1] = gy - gh / 2;
+        g[4 * i + 2] = gx + gw / 2; g[4 * i + 3] = gy + gh / 2;
+    }
+}
+
+/* ---- K1: 1-IoU anchor k-means.  NOT IN THE REFERENCE (clustering/cluster_prac.py:38-40
+ * only fixes the sklearn-style API).  Spec, parity unpinned:
+ *   d(b,c) = 1 - inter/(w*h + cw*ch - inter), inter = min(w,cw)*min(h,ch), fp32, I1 op order, no eps
+ *   assign = argmin_k d, ties -> lowest index
+ *   update = (sum_fx / count) with sum_fx = sum llrint(w * 2^32) as int64; centroid =
+ *            (float)((double)sum_fx / (double)count / 2^32); empty cluster keeps its centroid
+ *   inertia_fx = sum llrint(d * 2^32)  (int64)
+ * One Lloyd step: labels (in/out, uint8), acc[3k+2] = {sumw[k], sumh[k], cnt[k], changed, inertia_fx}
+ * (acc is ADDED to, so shards can accumulate into one buffer). */
+static inline float kdist(float w, float h, float cw, float ch)
+{
+    float inter = fminf(w, cw) * fminf(h, ch);
+    float uni = ((w * h) + (cw * ch)) - inter;
+    return 1.0f - inter / uni;
+}
+void orc_kmeans_step(const float *wh, int64_t n, const float *cent, int k, uint8_t *labels, int64_t *acc)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        float w = wh[2 * i], h = wh[2 * i + 1];
+        int best = 0; float bd = kdist(w, h, cent[0], cent[1]);
+        for (int c = 1; c < k; ++c) {
+            float d = kdist(w, h, cent[2 * c], cent[2 * c + 1]);
+            if (d < bd) { bd = d; best = c; }
+        }
+        acc[best] += llrint((double)w * 4294967296.0);
+        acc[k + best] += llrint((double)h * 4294967296.0);
+        acc[2 * k + best] += 1;
+        acc[3 * k] += (labels[i] != (uint8_t)best);
+        acc[3 * k + 1] += llrint((double)bd * 4294967296.0);
+        labels[i] = (uint8_t)best;
+    }
+}
+void orc_kmeans_update(const int64_t *acc, int k, float *cent)
+{
+    for (int c = 0; c < k; ++c) {
+        int64_t cnt = acc[2 * k + c];
+        if (cnt > 0) {
+            cent[2 * c] = (float)((double)acc[c] / (double)cnt / 4294967296.0);
+            cent[2 * c + 1] = (float)((double)acc[k + c] / (double)cnt / 4294967296.0);
+        }
+    }
+}

@@ -1,0 +1,145 @@
+"""Pins the CPU oracle (oracle/oracle.c) against vectors produced by executing the
+reference's own function bodies (oracle/gen_golden.py -> tests/golden/*.npz)."""
+import numpy as np
+import pytest
+
+
+def test_iou_tensor(golden, oracle):
+    g = golden("iou_tensor")
+    assert np.array_equal(oracle.iou_elementwise(g["a"], g["b"], 1e-7), g["iou_eps1e7"])
+    assert np.array_equal(oracle.iou_elementwise(g["a"], g["b"], 1e-6), g["iou_eps1e6"])
+    assert np.array_equal(oracle.iou_elementwise(g["a"].astype(np.float64), g["b"].astype(np.float64), 1e-7),
+                          g["iou_f64"])
+    assert np.array_equal(oracle.iou_elementwise(g["a_nan"], g["b_nan"]), g["iou_nan"], equal_nan=True)
+    # hand-derivable known answers
+    one = np.array([[0, 0, 1, 1]], np.float32)
+    assert oracle.iou_elementwise(one, one)[0] == np.float32(1.0) / (np.float32(1.0) + np.float32(1e-7))
+    assert oracle.iou_elementwise(one, one + 5)[0] == 0.0
+    pw = oracle.iou_pairwise(g["a"][:40], g["b"][:50])
+    for i in range(40):
+        assert np.array_equal(pw[i], oracle.iou_elementwise(np.repeat(g["a"][i:i + 1], 50, 0), g["b"][:50]))
+
+
+def test_iou_scalar(golden, oracle):
+    g = golden("iou_scalar")
+    got = np.array([oracle.iou_scalar(r, g["grt"]) for r in g["rois"]])
+    assert np.array_equal(got, g["iou"])
+    assert oracle.iou_scalar([0, 0, 10, 10], [10.0, 0, 20, 10]) == float(g["touch"]) == 0.0
+    for bb, raises in zip(g["bad_boxes"], g["bad_raises"]):
+        assert raises == 1
+        with pytest.raises(AssertionError):
+            oracle.iou_scalar(bb, g["grt"])
+
+
+def test_nms(golden, oracle):
+    g = golden("nms")
+    names = sorted(k[:-5] for k in g.files if k.endswith("_keep"))
+    assert len(names) >= 20
+    for name in names:
+        keep = oracle.nms(g[name + "_boxes"], g[name + "_scores"], float(g[name + "_thr"]))
+        assert np.array_equal(keep, g[name + "_keep"]), name
+    # the quirk probes of SURVEY §8(a) N1
+    assert g["one_keep"].size == 0 and list(g["two_disjoint_keep"]) == [0]
+    assert list(g["dup_then_disjoint_keep"]) == [0, 2]
+    t = golden("nms_frcnn_top")
+    r, s = oracle.nms_frcnn_top(list(t["rects"]), list(t["scores"]))
+    assert np.array_equal(r, t["best_rect"]) and s == float(t["best_score"])
+
+
+def test_decode_v1(golden, oracle):
+    g = golden("decode_v1")
+    for tag in "abc":
+        ct, pt = g[tag + "_thr"]
+        for i in range(g["output"].shape[0]):
+            box, lab, conf, score, tb, tl = oracle.yolo1_decode(g["output"][i], g["target"][i], ct, pt)
+            assert np.array_equal(box, g[f"{tag}_box_{i}"]), (tag, i)
+            assert np.array_equal(lab, g[f"{tag}_label_{i}"])
+            assert np.array_equal(conf, g[f"{tag}_conf_{i}"])
+            assert np.array_equal(score, g[f"{tag}_score_{i}"])
+            assert np.array_equal(tb, g[f"{tag}_tbox_{i}"])
+            assert tl == int(g[f"{tag}_tlabel_{i}"])
+    box, *_ = oracle.yolo1_decode(g["low_output"], g["target"][0], 0.2, 0.1)
+    assert box.shape == (0, 4)
+
+
+def test_evaluate_and_ap(golden, oracle):
+    g = golden("evaluate_v1")
+    det, tgt = oracle.evaluate_batch(g["output"], g["target"], 5, prob_threshold=0.01, nms_threshold=0.3)
+    for c in range(5):
+        assert np.array_equal(np.array(det[c], np.float64).reshape(-1, 6), g[f"detects_{c}"]), c
+        assert np.array_equal(np.array(tgt[c], np.float64).reshape(-1, 6), g[f"targets_{c}"]), c
+    assert np.allclose(oracle.average_precision(det, tgt, 0.05), g["aps_iou005"], rtol=0, atol=1e-12)
+    assert np.allclose(oracle.average_precision(det, tgt, 0.5), g["aps_iou05"], rtol=0, atol=1e-12)
+
+
+def test_roipool(golden, oracle):
+    g = golden("roipool")
+    out, arg = oracle.roipool_fwd(g["img"], g["rois"], g["idx"], 7, "max")
+    assert np.array_equal(out, g["max_out"])
+    assert np.array_equal(arg, g["max_argmax"])
+    avg, _ = oracle.roipool_fwd(g["img"], g["rois"], g["idx"], 7, "avg")
+    np.testing.assert_allclose(avg, g["avg_out"], rtol=1e-6, atol=1e-7)
+    gin = oracle.roipool_bwd(g["grad_out"], arg, g["img"].shape, g["rois"], g["idx"], 7, "max")
+    np.testing.assert_allclose(gin, g["max_grad_in"], rtol=1e-5, atol=1e-5)
+    gin = oracle.roipool_bwd(g["grad_out"], None, g["img"].shape, g["rois"], g["idx"], 7, "avg")
+    np.testing.assert_allclose(gin, g["avg_grad_in"], rtol=1e-5, atol=1e-5)
+    assert int(g["empty_raises"]) == 1
+    with pytest.raises(RuntimeError):
+        oracle.roipool_fwd(g["img"], g["empty_rois"], g["idx"][:2])
+
+
+def test_yolo2_get_point(golden, oracle):
+    g = golden("yolo2_get_point")
+    pts, enc = oracle.yolo2_get_point(g["bbox"])
+    assert np.array_equal(pts, g["points"])
+    assert np.array_equal(enc, g["enc"])
+    # decode_v2 is the inverse (parity unpinned: round trip only)
+    xyxy = oracle.yolo2_decode_cells(pts, enc)
+    want = np.concatenate([g["bbox"][:, :2], g["bbox"][:, :2] + g["bbox"][:, 2:]], 1)
+    np.testing.assert_allclose(xyxy, want, rtol=0, atol=2e-6)
+
+
+def test_rcnn_boxreg(golden, oracle):
+    g = golden("rcnn_boxreg")
+    np.testing.assert_allclose(oracle.rcnn_calcul(g["positive"], g["grt"]), g["t_target"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(oracle.rcnn_decode(g["p_rect"], g["tset"], 0).reshape(g["g_rect_rcnn"].shape),
+                               g["g_rect_rcnn"], rtol=1e-6, atol=1e-4)
+    np.testing.assert_allclose(oracle.rcnn_decode(g["p_rect"], g["tset"], 1).reshape(g["g_rect_frcnn"].shape),
+                               g["g_rect_frcnn"], rtol=1e-6, atol=1e-4)
+
+
+def test_do_ss_quota(golden, oracle):
+    g = golden("do_ss_quota")
+    rois, grt, labels = oracle.label_proposals(g["rects"], g["bbox"], int(g["label"]), int(g["min_num"]), 0.1, 0.1, 2)
+    assert np.array_equal(rois, g["rcnn_rois"]) and np.array_equal(labels, g["rcnn_labels"])
+    assert np.array_equal(grt, g["rcnn_grt"])
+    rois, grt, labels = oracle.label_proposals(g["rects"], g["bbox"], int(g["label"]), int(g["min_num"]), 0.5, 0.1, 1,
+                                               require_full=True)
+    assert np.array_equal(rois, g["frcnn_rois"]) and np.array_equal(labels, g["frcnn_labels"])
+    rois, _, labels = oracle.label_proposals(g["rects"][:30], g["bbox"], 3, 50, 0.5, 0.1, 1, require_full=True)
+    assert rois.shape == (0, 4) and labels.size == 0
+
+
+def test_kmeans_spec_selfconsistency(oracle):
+    """1-IoU k-means is NOT in the reference (parity unpinned): only the spec's own invariants."""
+    from vision_amd import workloads as wl
+    wh = wl.anchor_wh(0, 20000)
+    cent, labels, n_iter, inertia = oracle.kmeans_fit(wh, 5, 42)
+    assert cent.shape == (5, 2) and labels.shape == (20000,) and 1 <= n_iter <= 300
+    # converged: one more step changes nothing
+    lab8 = labels.astype(np.uint8)
+    acc = oracle.kmeans_step(wh, cent, lab8)
+    assert acc[15] == 0
+    # sharded accumulation is bit-identical to the single pass (integer sums)
+    acc2 = np.zeros(17, np.int64)
+    l2 = labels.astype(np.uint8)
+    for s in range(4):
+        oracle.kmeans_step(wh[s * 5000:(s + 1) * 5000], cent, l2[s * 5000:(s + 1) * 5000], acc2)
+    assert np.array_equal(acc, acc2)
+    assert np.array_equal(oracle.kmeans_update(acc, cent), cent)
+
+
+def test_cluster_demo_api_shape(golden):
+    g = golden("cluster_demo")
+    assert g["labels"].shape == (100,) and g["centers"].shape == (5, 2)
+    assert set(np.unique(g["labels"])) == set(range(5))

@@ -1,0 +1,110 @@
+"""Seeded synthetic inputs for the five BASELINE.json configs.
+
+Pure NumPy on the host: tests, the golden-vector generator and bench.py all draw
+their inputs from here so that "same seeded inputs" means the same bytes everywhere.
+Nothing in this file computes a result of the hot path.
+"""
+import numpy as np
+
+# ---------------------------------------------------------------- scores
+def tiefree_scores(seed, n):
+    """fp32 scores in (0,1), pairwise distinct (the reference sort is unstable,
+    yolo/yolo_v1/yolo.py:194, so fixtures must be tie-free)."""
+    rng = np.random.default_rng(seed)
+    if n == 0:
+        return np.zeros((0,), np.float32)
+    s = (rng.permutation(n).astype(np.float64) + rng.uniform(0.25, 0.75, n)) / n
+    s = s.astype(np.float32)
+    assert np.unique(s).size == n
+    return s
+
+
+# ---------------------------------------------------------------- config 1 / 3
+def frcnn_rois(seed, n=2000):
+    """Normalised xyxy RoIs, float64, all non-empty after floor/ceil on a 38x50 map."""
+    rng = np.random.default_rng(seed)
+    xy = rng.uniform(0.0, 0.7, (n, 2))
+    wh = rng.uniform(0.02, 0.30, (n, 2))
+    return np.concatenate([xy, xy + wh], axis=1)
+
+
+def frcnn_feature_map(seed, b=1, c=512, h=38, w=50):
+    rng = np.random.default_rng(1000 + seed)
+    return rng.standard_normal((b, c, h, w), dtype=np.float32)
+
+
+def frcnn_proposals(seed, n=2000):
+    """boxes fp32 xyxy (the RoIs rounded to fp32) + tie-free scores."""
+    return frcnn_rois(seed, n).astype(np.float32), tiefree_scores(seed + 7, n)
+
+
+# ---------------------------------------------------------------- config 2
+def yolo1_encode(bb, label, num_classes, S=7, B=2):
+    """Target builder used only to make synthetic `target` tensors with one object
+    cell (same layout the reference's encode produces, modules.py:151-174)."""
+    bb = np.asarray(bb, np.float64).copy()
+    N = 5 * B + num_classes
+    bb[:2] += bb[2:] / 2
+    t = np.zeros((S, S, N))
+    cxy, wh = bb[:2], bb[2:]
+    ij = (cxy * S).astype(int)
+    i, j = ij
+    xy_cell = (cxy - ij * (1 / S)) / (1 / S)
+    for b in range(B):
+        t[j, i, b * 5:(b + 1) * 5] = np.hstack([xy_cell, wh, 1])
+    t[j, i, B * 5 + label - 1] = 1
+    return t
+
+
+def yolo1_batch(seed, batch=64, num_classes=5, one_slot=False):
+    """output ~ U(0,1) (sigmoid range) (batch,7,7,10+C) fp32 and a one-object target.
+
+    Both box slots of a cell share the cell's class score, which is the NMS sort key
+    (yolo/yolo_v1/yolo.py:168,173,194): with both slots alive the reference's unstable
+    sort sees ties and its order is implementation-defined.  `one_slot=True` zeroes the
+    confidence of one random slot per cell so that parity fixtures are tie-free."""
+    rng = np.random.default_rng(seed)
+    out = rng.uniform(0, 1, (batch, 7, 7, 10 + num_classes)).astype(np.float32)
+    if one_slot:
+        dead = rng.integers(0, 2, (batch, 7, 7))
+        out[..., 4][dead == 0] = 0.0
+        out[..., 9][dead == 1] = 0.0
+    tgt = np.zeros_like(out)
+    for b in range(batch):
+        xy = rng.uniform(0.05, 0.6, 2)
+        wh = rng.uniform(0.05, 0.35, 2)
+        lab = int(rng.integers(1, num_classes + 1))
+        tgt[b] = yolo1_encode(np.concatenate([xy, wh]), lab, num_classes).astype(np.float32)
+    return out, tgt
+
+
+# ---------------------------------------------------------------- config 4
+def anchor_wh(seed, n):
+    rng = np.random.default_rng(seed)
+    wh = np.exp(rng.normal(-1.5, 0.6, (n, 2)))
+    return np.clip(wh, 1e-3, 1.0).astype(np.float32)
+
+
+# ---------------------------------------------------------------- config 5
+def stress_boxes(seed, n=65536, dense=False):
+    rng = np.random.default_rng(seed)
+    xy = rng.uniform(0.0, 0.95, (n, 2))
+    wh = rng.uniform(0.05, 0.3, (n, 2)) if dense else rng.uniform(0.005, 0.05, (n, 2))
+    boxes = np.concatenate([xy, xy + wh], axis=1).astype(np.float32)
+    return boxes, tiefree_scores(seed + 11, n)
+
+
+# ---------------------------------------------------------------- generic
+def random_boxes(seed, n, degenerate=True):
+    """Unit-square boxes; with `degenerate` a few inverted / zero-area / duplicate ones."""
+    rng = np.random.default_rng(seed)
+    xy = rng.uniform(0, 0.8, (n, 2))
+    wh = rng.uniform(0.01, 0.4, (n, 2))
+    b = np.concatenate([xy, xy + wh], axis=1).astype(np.float32)
+    if degenerate and n >= 8:
+        b[1] = b[0]                       # duplicate
+        b[2, 2:] = b[2, :2]               # zero area
+        b[3] = b[3, [2, 3, 0, 1]]         # inverted corners
+        b[4] = [0, 0, 1, 1]
+        b[5] = [0, 0, 1, 1]
+    return b
