@@ -1,0 +1,138 @@
+/* detgeom.h — flat C ABI of libdetgeom.so, the MI355X (gfx950) box-geometry library.
+ *
+ * The reference (crapine1119/vision) is pure Python and has NO FFI / plugin boundary
+ * (SURVEY.md §8(b)); its boundary is a set of Python callables.  Each entry point below
+ * names the reference callable (file:line, relative to the reference repo) whose
+ * arithmetic it replaces; the modules of vision_amd/ re-export those callables with the
+ * reference's signatures and reaches these symbols through ctypes (vision_amd/_abi.py).
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller unless marked "host";
+ *  - sizes are int64_t, the last argument is the HIP stream (hipStream_t as void*);
+ *  - calls are asynchronous on that stream and allocate nothing: scratch memory comes in
+ *    through (ws, ws_bytes), sized by the matching dg_*_workspace_bytes();
+ *  - return value: DG_OK or a negative DG_E* code; dg_last_error() gives the text
+ *    (thread-local).  No exceptions and no torch types cross this boundary.
+ */
+#ifndef DETGEOM_H
+#define DETGEOM_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DG_OK 0
+#define DG_EINVAL (-1)    /* bad argument (null pointer, negative size, unsupported shape) */
+#define DG_EEMPTYROI (-2) /* reported through the status word of dg_roi_windows */
+#define DG_ENOMEM (-3)    /* workspace too small */
+#define DG_EHIP (-4)      /* a HIP runtime call / launch failed */
+
+#define DG_POOL_AVG 0 /* rcnn/fast_rcnn.py:354 as written (AdaptiveAvgPool2d) */
+#define DG_POOL_MAX 1 /* north_star: max + argmax */
+
+typedef void *dg_stream_t;
+
+const char *dg_version(void);
+/* copies the calling thread's last error text into buf (host); returns its length */
+int dg_last_error(char *buf, size_t n);
+
+/* ---------------------------------------------------------------- IoU
+ * I1 get_iou(bb1,bb2): yolo/yolo_v1/modules.py:73-98 (eps 1e-7), copy yolo/yolo_v2/utils.py:238-263;
+ * I2 Loss.get_iou: yolo/yolo_v1/modules.py:208-228 (eps 1e-6).  bb*: (n,4) xyxy, out: (n). */
+int dg_iou_elementwise_f32(const float *bb1, const float *bb2, int64_t n, float eps, float *out, dg_stream_t s);
+int dg_iou_elementwise_f64(const double *bb1, const double *bb2, int64_t n, double eps, double *out, dg_stream_t s);
+/* N x M matrix of I1: row i is what yolo/yolo_v1/yolo.py:200 evaluates for head box i.
+ * a: (n,4), b: (m,4), out: (n,m) row-major. */
+int dg_iou_pairwise_f32(const float *a, int64_t n, const float *b, int64_t m, float eps, float *out, dg_stream_t s);
+/* I3 get_iou(roi, grt) scalar, float64, no eps: rcnn/utils.py:50-67 (dup rcnn/fast_rcnn.py:62-79),
+ * evaluated for n rois against one ground-truth box (the loop of rcnn/rcnn.py:35-40).
+ * rois: (n,4) float64 xyxy, grt: (4) float64; out: (n) float64; flags: (n) int32, 1 where the
+ * reference's asserts (:51-54, :65-66) would fire, else 0. */
+int dg_iou_rois_vs_gt_f64(const double *rois, const double *grt, int64_t n, double *out, int32_t *flags, dg_stream_t s);
+
+/* ---------------------------------------------------------------- NMS
+ * N1 nms(out_box,out_score,threshold): yolo/yolo_v1/yolo.py:188-203, batched over images.
+ * boxes: (batch,nmax,4) fp32 xyxy; scores: (batch,nmax); counts: (batch) int32 candidates per image
+ * or NULL (= nmax each).  keep: (batch,nmax) int64 indices into the image's unsorted input in
+ * descending-score order (ties: lower index first); keep_count: (batch) int32.
+ * quirk_drop_last=1 reproduces the reference's `while numel()>1` (the candidate left alone is dropped).
+ * The compare is `iou < (float)threshold` exactly as torch evaluates :201. */
+size_t dg_nms_workspace_bytes(int64_t batch, int64_t nmax);
+int dg_nms_batched_f32(const float *boxes, const float *scores, const int32_t *counts, int64_t batch, int64_t nmax,
+                       float threshold, int quirk_drop_last, int64_t *keep, int32_t *keep_count,
+                       void *ws, size_t ws_bytes, dg_stream_t s);
+/* phases of the above, exposed for measurement (bench.py) and tests; same workspace */
+int dg_nms_phase_sort(const float *boxes, const float *scores, const int32_t *counts, int64_t batch, int64_t nmax,
+                      void *ws, size_t ws_bytes, dg_stream_t s);
+int dg_nms_phase_mask(const int32_t *counts, int64_t batch, int64_t nmax, float threshold,
+                      void *ws, size_t ws_bytes, dg_stream_t s);
+int dg_nms_phase_reduce(const int32_t *counts, int64_t batch, int64_t nmax, int quirk_drop_last,
+                        int64_t *keep, int32_t *keep_count, void *ws, size_t ws_bytes, dg_stream_t s);
+
+/* ---------------------------------------------------------------- YOLOv1 decode
+ * D1 decode(output,target,conf_threshold,prob_threshold): yolo/yolo_v1/yolo.py:115-186, batched.
+ * output/target: (batch,7,7,10+C) fp32 (target may be NULL).  Per image: out_box (98,4) fp32,
+ * out_label (98) int64, out_conf (98), out_score (98), out_count int32 (M <= 98: slot-1 hits in
+ * row-major cell order then slot-2 hits); tgt_box (4) float64, tgt_label int64 (1-based). */
+int dg_yolo1_decode_f32(const float *output, const float *target, int64_t batch, int64_t num_classes,
+                        float conf_threshold, float prob_threshold,
+                        float *out_box, int64_t *out_label, float *out_conf, float *out_score, int32_t *out_count,
+                        double *tgt_box, int64_t *tgt_label, dg_stream_t s);
+
+/* ---------------------------------------------------------------- YOLOv2
+ * get_point(output_size,bbox): yolo/yolo_v2/utils.py:228-234 (encoder, 13x13 hard-coded).
+ * bbox: (n,4) xywh fp32 -> points (n,2) int64, enc (n,4) fp32 = [normed xy, wh]. */
+int dg_yolo2_get_point_f32(const float *bbox, int64_t n, int64_t *points, float *enc, dg_stream_t s);
+/* decode (NOT in the reference; build-defined inverse of get_point): xyxy (n,4). */
+int dg_yolo2_decode_cells_f32(const int64_t *points, const float *enc, int64_t n, float *xyxy, dg_stream_t s);
+/* standard anchor decode (NOT in the reference): pred (G,G,A,5+C), anchors (A,2) -> xyxy (G*G*A,4), conf. */
+int dg_yolo2_decode_anchor_f32(const float *pred, int64_t G, int64_t A, int64_t C, const float *anchors,
+                               float *xyxy, float *conf, dg_stream_t s);
+
+/* ---------------------------------------------------------------- RoI pooling
+ * R1 slowroipool.foward(img,roi_ary,roi_idx): rcnn/fast_rcnn.py:351-377.
+ * dg_roi_windows does :366-369 (+ python slice clamping): rois (n,4) float64 normalised xyxy,
+ * roi_idx (n) int64 -> win (n,5) int32 = {x1,y1,x2,y2,image}.  *status (device int32, zeroed by the
+ * caller) is OR-ed with 1 if some crop is empty (the reference raises RuntimeError there) and with 2 if
+ * an image index is out of range. */
+int dg_roi_windows(const double *rois, const int64_t *roi_idx, int64_t n, int64_t B, int64_t H, int64_t W,
+                   int32_t *win, int32_t *status, dg_stream_t s);
+/* (B,C,H,W) -> (B,H,W,C) staging copy used by the forward kernel (lanes = channels). */
+int dg_nchw_to_nhwc_f32(const float *src, int64_t B, int64_t C, int64_t H, int64_t W, float *dst, dg_stream_t s);
+/* forward: img_nhwc (B,H,W,C), win from dg_roi_windows; out (n,C,P,P) fp32; argmax (n,C,P,P) int32
+ * = flat index y*W+x in the feature-map plane (DG_POOL_MAX only, may be NULL).  P must be 7. */
+int dg_roipool_fwd_f32(const float *img_nhwc, int64_t B, int64_t C, int64_t H, int64_t W,
+                       const int32_t *win, int64_t n, int64_t P, int mode, float *out, int32_t *argmax, dg_stream_t s);
+/* R2 backward (autograd in the reference).  grad_out (n,C,P,P), argmax from the forward (max mode);
+ * grad_in (B,C,H,W) is overwritten (not accumulated).  Workspace holds the per-image RoI lists. */
+size_t dg_roipool_bwd_workspace_bytes(int64_t B, int64_t n);
+int dg_roipool_bwd_f32(const float *grad_out, const int32_t *argmax, const int32_t *win, int64_t n,
+                       int64_t B, int64_t C, int64_t H, int64_t W, int64_t P, int mode, float *grad_in,
+                       void *ws, size_t ws_bytes, dg_stream_t s);
+
+/* ---------------------------------------------------------------- anchor k-means (1-IoU)
+ * K1: the reference only fixes the sklearn-style API (clustering/cluster_prac.py:38-40); the 1-IoU
+ * Lloyd step is build-defined (spec: oracle/oracle.c orc_kmeans_step / SURVEY.md §8(a) K1).
+ * wh (n,2) fp32; cent (k,2) fp32; labels (n) uint8 in/out; acc (3k+2) int64 =
+ * {sum_w[k], sum_h[k], count[k], changed, inertia_fx} is OVERWRITTEN with this shard's sums
+ * (all-reduce it across ranks, then call dg_kmeans_update).  k <= 16. */
+size_t dg_kmeans_workspace_bytes(int64_t n, int64_t k);
+int dg_kmeans_iou_step(const float *wh, int64_t n, const float *cent, int64_t k, uint8_t *labels, int64_t *acc,
+                       void *ws, size_t ws_bytes, dg_stream_t s);
+/* centroid = sum/count (int64 fixed point 2^32 -> fp32); empty cluster keeps its centroid.
+ * history (may be NULL): history[slot] = acc[3k] (changed count of this iteration). */
+int dg_kmeans_update(const int64_t *acc, int64_t k, float *cent, int64_t *history, int64_t slot, dg_stream_t s);
+int dg_kmeans_labels_i32(const uint8_t *labels, int64_t n, int32_t *out, dg_stream_t s);
+
+/* ---------------------------------------------------------------- R-CNN box regression ("next" rows)
+ * calcul(positive,grt): rcnn/utils.py:153-171; inverse: rcnn/rcnn.py:287-310 (variant 0) and
+ * rcnn/fast_rcnn.py:543-560 (variant 1). */
+int dg_rcnn_calcul_f32(const float *positive, int64_t n, const float *grt, float *t, dg_stream_t s);
+int dg_rcnn_decode_f32(const int32_t *p_rect, const float *tset, int64_t n, int variant, float *g, dg_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DETGEOM_H */

@@ -1,0 +1,295 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the committed
+golden vectors.  Bars (BASELINE.json north_star): NMS keep indices, RoI argmax, k-means
+assignments bit-exact; IoU / pooled values / centroids within 1e-6 relative (we assert bit-exact
+where the arithmetic is IEEE-identical and say so)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from vision_amd import workloads as wl  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def va():
+    import vision_amd
+    from vision_amd import _abi, ops, yolo_v1, yolo_v2, rcnn_utils, fast_rcnn, cluster
+    _abi.load()
+    assert torch.cuda.is_available()
+    return vision_amd
+
+
+def test_single_hip_runtime(va):
+    """libdetgeom must share torch's HIP runtime (one libamdhip64 mapped), or streams would not be valid."""
+    with open("/proc/self/maps") as f:
+        libs = {line.split()[-1] for line in f if "libamdhip64" in line}
+    assert len(libs) == 1, libs
+    assert any("libdetgeom.so" in line for line in open("/proc/self/maps"))
+
+
+# ------------------------------------------------------------------ IoU
+def test_iou_elementwise_golden(va, golden):
+    from vision_amd import yolo_v1, yolo_v2
+    g = golden("iou_tensor")
+    a, b = torch.from_numpy(g["a"]), torch.from_numpy(g["b"])
+    got = yolo_v1.get_iou(a, b)
+    assert got.dtype == torch.float32 and not got.is_cuda
+    assert np.array_equal(got.numpy(), g["iou_eps1e7"])          # bit-exact
+    assert np.array_equal(yolo_v2.get_iou(a.cuda(), b.cuda()).cpu().numpy(), g["iou_eps1e7"])
+    assert np.array_equal(yolo_v1.Loss(2, 5).get_iou(a, b).numpy(), g["iou_eps1e6"])
+    got64 = yolo_v1.get_iou(a.double(), b.double())
+    assert got64.dtype == torch.float64
+    assert np.array_equal(got64.numpy(), g["iou_f64"])
+    nan = yolo_v1.get_iou(torch.from_numpy(g["a_nan"]), torch.from_numpy(g["b_nan"])).numpy()
+    assert np.array_equal(nan, g["iou_nan"], equal_nan=True)
+    assert yolo_v1.get_iou(torch.zeros(0, 4), torch.zeros(0, 4)).shape == (0,)
+
+
+@pytest.mark.parametrize("n,m", [(1, 1), (63, 65), (64, 1024), (130, 1027), (257, 2052)])
+def test_iou_pairwise_vs_oracle(va, oracle, n, m):
+    from vision_amd import ops
+    a, b = wl.random_boxes(n, n), wl.random_boxes(1000 + m, m)
+    got = ops.iou_pairwise(torch.from_numpy(a), torch.from_numpy(b)).cpu().numpy()
+    assert np.array_equal(got, oracle.iou_pairwise(a, b))        # bit-exact
+
+
+def test_iou_scalar_golden(va, golden):
+    from vision_amd import rcnn_utils
+    g = golden("iou_scalar")
+    iou, flags = rcnn_utils.iou_many(g["rois"], g["grt"])
+    assert np.array_equal(iou, g["iou"]) and not flags.any()
+    assert rcnn_utils.get_iou([0, 0, 10, 10], np.array([10.0, 0, 20, 10])) == 0.0
+    assert rcnn_utils.get_iou(list(g["rois"][0]), g["grt"]) == g["iou"][0]
+    for bb in g["bad_boxes"]:
+        with pytest.raises(AssertionError):
+            rcnn_utils.get_iou(bb, g["grt"])
+
+
+# ------------------------------------------------------------------ NMS
+def test_nms_golden(va, golden):
+    from vision_amd import yolo_v1
+    g = golden("nms")
+    names = sorted(k[:-5] for k in g.files if k.endswith("_keep"))
+    for name in names:
+        keep = yolo_v1.nms(torch.from_numpy(g[name + "_boxes"]), torch.from_numpy(g[name + "_scores"]), float(g[name + "_thr"]))
+        assert keep.dtype == torch.int64
+        assert np.array_equal(keep.numpy(), g[name + "_keep"]), name
+    assert yolo_v1.nms([], [], 0.3).numel() == 0
+
+
+@pytest.mark.parametrize("n,dense,thr", [(4096, True, 0.5), (4097, False, 0.5), (10000, False, 0.3), (20000, True, 0.7)])
+def test_nms_large_vs_oracle(va, oracle, n, dense, thr):
+    """exercises the global bitonic sort and the 1024-thread reduce"""
+    from vision_amd import yolo_v1
+    b, s = wl.stress_boxes(n, n, dense=dense)
+    keep = yolo_v1.nms(torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda(), thr)
+    assert keep.is_cuda
+    assert np.array_equal(keep.cpu().numpy(), oracle.nms(b, s, thr)), (n, dense, thr)
+
+
+def test_nms_batched_ragged_vs_oracle(va, oracle):
+    from vision_amd import ops
+    B, N = 9, 300
+    rng = np.random.default_rng(5)
+    counts = np.array([0, 1, 2, 64, 65, 128, 299, 300, 37], np.int32)
+    boxes = np.stack([wl.random_boxes(50 + i, N) for i in range(B)])
+    scores = np.stack([wl.tiefree_scores(60 + i, N) for i in range(B)])
+    for quirk in (True, False):
+        keep, cnt = ops.nms_batched(torch.from_numpy(boxes), torch.from_numpy(scores), torch.from_numpy(counts), 0.4, quirk)
+        keep, cnt = keep.cpu().numpy(), cnt.cpu().numpy()
+        for i in range(B):
+            want = oracle.nms(boxes[i, :counts[i]], scores[i, :counts[i]], 0.4, quirk)
+            assert cnt[i] == len(want) and np.array_equal(keep[i, :cnt[i]], want), (i, quirk)
+
+
+def test_nms_frcnn_top(va, golden):
+    from vision_amd import fast_rcnn
+    t = golden("nms_frcnn_top")
+    r, s = fast_rcnn.nms(list(t["rects"]), list(t["scores"]))
+    assert np.array_equal(r, t["best_rect"]) and s == float(t["best_score"])
+
+
+# ------------------------------------------------------------------ decode / evaluate / ap
+def test_decode_golden(va, golden):
+    from vision_amd import yolo_v1
+    g = golden("decode_v1")
+    for tag in "abc":
+        ct, pt = g[tag + "_thr"]
+        for i in range(g["output"].shape[0]):
+            r = yolo_v1.decode(torch.from_numpy(g["output"][i]), torch.from_numpy(g["target"][i]), ct, pt)
+            box, lab, conf, score, tb, tl = r
+            want = g[f"{tag}_box_{i}"]
+            if len(want) == 0:
+                assert box == [] and lab == []
+                continue
+            assert box.dtype == torch.float32 and lab.dtype == torch.int64 and tb.dtype == torch.float64
+            assert np.array_equal(box.numpy(), want), (tag, i)
+            assert np.array_equal(lab.numpy(), g[f"{tag}_label_{i}"])
+            assert np.array_equal(conf.numpy(), g[f"{tag}_conf_{i}"])
+            assert np.array_equal(score.numpy(), g[f"{tag}_score_{i}"])
+            assert np.array_equal(tb.numpy(), g[f"{tag}_tbox_{i}"]) and tl == int(g[f"{tag}_tlabel_{i}"])
+    r = yolo_v1.decode(torch.from_numpy(g["low_output"]), torch.from_numpy(g["target"][0]), 0.2, 0.1)
+    assert r[0] == [] and r[3] == []
+
+
+def test_evaluate_and_ap_golden(va, golden):
+    from vision_amd import yolo_v1
+    g = golden("evaluate_v1")
+    det, tgt = yolo_v1.evaluate_batch(torch.from_numpy(g["output"]).cuda(), torch.from_numpy(g["target"]).cuda(), 5,
+                                      prob_threshold=0.01, nms_threshold=0.3)
+    for c in range(5):
+        assert np.array_equal(np.array(det[c], np.float64).reshape(-1, 6), g[f"detects_{c}"]), c
+        assert np.array_equal(np.array(tgt[c], np.float64).reshape(-1, 6), g[f"targets_{c}"]), c
+    assert np.allclose(yolo_v1.ap(det, tgt, 0.05), g["aps_iou005"], rtol=0, atol=1e-12)
+    assert np.allclose(yolo_v1.ap(det, tgt, 0.5), g["aps_iou05"], rtol=0, atol=1e-12)
+
+
+def test_decode_nms_config2_vs_oracle(va, oracle):
+    """config 2 at full size (batch 64); ties between the two slots of a cell are ordered lower index first."""
+    from vision_amd import yolo_v1
+    out, tgt = wl.yolo1_batch(0, 64)
+    box, label, conf, score, count, keep, kcnt, tbox, tlabel = [
+        t.cpu().numpy() for t in yolo_v1.decode_nms_batched(torch.from_numpy(out), torch.from_numpy(tgt), 0.2, 0.01, 0.3)]
+    for i in range(64):
+        b, l, c, s, tb, tl = oracle.yolo1_decode(out[i], tgt[i], 0.2, 0.01)
+        assert count[i] == len(b) and np.array_equal(box[i, :count[i]], b) and np.array_equal(label[i, :count[i]], l)
+        want = oracle.nms(b, s, 0.3)
+        assert kcnt[i] == len(want) and np.array_equal(keep[i, :kcnt[i]], want), i
+        assert np.array_equal(tbox[i], tb) and tlabel[i] == tl
+
+
+# ------------------------------------------------------------------ RoI pool
+def test_roipool_golden(va, golden):
+    from vision_amd import fast_rcnn
+    g = golden("roipool")
+    img = torch.from_numpy(g["img"])
+    m = fast_rcnn.slowroipool((7, 7), mode="max")
+    out = m.foward(img, g["rois"], g["idx"])
+    assert out.shape == (96, 8, 7, 7) and not out.is_cuda
+    assert np.array_equal(out.numpy(), g["max_out"])                         # bit-exact
+    assert np.array_equal(m.argmax.cpu().numpy(), g["max_argmax"])           # bit-exact
+    avg = fast_rcnn.slowroipool((7, 7), mode="avg").foward(img.cuda(), g["rois"], g["idx"])
+    np.testing.assert_allclose(avg.cpu().numpy(), g["avg_out"], rtol=1e-6, atol=1e-7)
+    # backward through autograd, both modes
+    for mode, key in (("max", "max_grad_in"), ("avg", "avg_grad_in")):
+        x = img.cuda().requires_grad_(True)
+        y = fast_rcnn.slowroipool((7, 7), mode=mode)(x, g["rois"], g["idx"])
+        y.backward(torch.from_numpy(g["grad_out"]).cuda())
+        np.testing.assert_allclose(x.grad.cpu().numpy(), g[key], rtol=1e-5, atol=1e-5)
+    with pytest.raises(RuntimeError):
+        m.foward(img, g["empty_rois"], g["idx"][:2])
+
+
+def test_roipool_config1_vs_oracle(va, oracle):
+    """config 1 shape: 512x38x50 map, 2000 RoIs (oracle takes ~2 s)"""
+    from vision_amd import ops
+    img = wl.frcnn_feature_map(0)
+    rois = wl.frcnn_rois(0)
+    idx = np.zeros(2000, np.int64)
+    x = torch.from_numpy(img).cuda()
+    win, status = ops.roi_windows(rois, idx, 1, 38, 50, x.device)
+    assert int(status.item()) == 0
+    out, arg = ops.roipool_forward(x, win, "max")
+    want, warg = oracle.roipool_fwd(img, rois, idx, 7, "max")
+    assert np.array_equal(out.cpu().numpy(), want)
+    assert np.array_equal(arg.cpu().numpy(), warg)
+    rng = np.random.default_rng(1)
+    gout = rng.standard_normal(want.shape, dtype=np.float32)
+    gin = ops.roipool_backward(torch.from_numpy(gout).cuda(), arg, win, img.shape, "max").cpu().numpy()
+    wgin = oracle.roipool_bwd(gout, warg, img.shape, rois, idx, 7, "max")
+    np.testing.assert_allclose(gin, wgin, rtol=1e-4, atol=1e-4)     # fp32 sums of ~50 terms in a different order
+
+
+def test_roipool_odd_channels_and_batch(va, oracle):
+    from vision_amd import ops
+    rng = np.random.default_rng(2)
+    img = rng.standard_normal((3, 70, 20, 24), dtype=np.float32)      # C not a multiple of 4 nor 64
+    img[0, 3, 5, 5] = np.nan
+    rois = wl.frcnn_rois(9, 50)
+    idx = rng.integers(0, 3, 50).astype(np.int64)
+    x = torch.from_numpy(img).cuda()
+    win, status = ops.roi_windows(rois, idx, 3, 20, 24, x.device)
+    for mode in ("max", "avg"):
+        out, arg = ops.roipool_forward(x, win, mode)
+        want, warg = oracle.roipool_fwd(img, rois, idx, 7, mode)
+        if mode == "max":
+            assert np.array_equal(out.cpu().numpy(), want, equal_nan=True) and np.array_equal(arg.cpu().numpy(), warg)
+        else:
+            np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-6, atol=1e-7)
+
+
+# ------------------------------------------------------------------ YOLOv2 / R-CNN box regression
+def test_yolo2_get_point_golden(va, golden, oracle):
+    from vision_amd import yolo_v2
+    g = golden("yolo2_get_point")
+    pts, enc = yolo_v2.get_point(56, torch.from_numpy(g["bbox"]))
+    assert pts.dtype == torch.int64
+    assert np.array_equal(pts.numpy(), g["points"])
+    np.testing.assert_allclose(enc.numpy(), g["enc"], rtol=1e-6, atol=1e-6)
+    p1, e1 = yolo_v2.get_point(56, torch.from_numpy(g["bbox"][0]))
+    assert p1.shape == (2,) and e1.shape == (4,)
+    xyxy = yolo_v2.decode_v2(pts, enc).numpy()
+    assert np.array_equal(xyxy, oracle.yolo2_decode_cells(pts.numpy(), enc.numpy()))
+    rng = np.random.default_rng(0)
+    pred = rng.normal(0, 1, (13, 13, 5, 10)).astype(np.float32)
+    anchors = rng.uniform(0.05, 0.5, (5, 2)).astype(np.float32)
+    bx, cf = yolo_v2.decode_anchor(torch.from_numpy(pred), torch.from_numpy(anchors))
+    wb, wc = oracle.yolo2_decode_anchor(pred, anchors)
+    np.testing.assert_allclose(bx.numpy(), wb, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(cf.numpy(), wc, rtol=1e-6, atol=1e-6)
+
+
+def test_rcnn_boxreg_golden(va, golden):
+    from vision_amd import rcnn_utils
+    g = golden("rcnn_boxreg")
+    t = rcnn_utils.calcul(torch.from_numpy(g["positive"]), torch.from_numpy(g["grt"]))
+    np.testing.assert_allclose(t.numpy(), g["t_target"], rtol=1e-6, atol=1e-6)
+    for variant, key in ((0, "g_rect_rcnn"), (1, "g_rect_frcnn")):
+        got = rcnn_utils.decode_boxes(torch.from_numpy(g["p_rect"]), torch.from_numpy(g["tset"]), variant)
+        np.testing.assert_allclose(got.numpy(), g[key], rtol=1e-6, atol=1e-4)
+
+
+def test_label_proposals_golden(va, golden):
+    from vision_amd import rcnn_utils
+    g = golden("do_ss_quota")
+    rois, grt, labels = rcnn_utils.label_proposals(g["rects"], g["bbox"], int(g["label"]), int(g["min_num"]), 0.1, 0.1, 2)
+    assert np.array_equal(rois, g["rcnn_rois"]) and np.array_equal(labels, g["rcnn_labels"]) and np.array_equal(grt, g["rcnn_grt"])
+    rois, grt, labels = rcnn_utils.label_proposals(g["rects"], g["bbox"], int(g["label"]), int(g["min_num"]), 0.5, 0.1, 1, True)
+    assert np.array_equal(rois, g["frcnn_rois"]) and np.array_equal(labels, g["frcnn_labels"])
+
+
+# ------------------------------------------------------------------ k-means
+@pytest.mark.parametrize("n,k", [(1000, 5), (200000, 5), (50000, 9)])
+def test_kmeans_vs_oracle(va, oracle, n, k):
+    from vision_amd import cluster
+    wh = wl.anchor_wh(3, n)
+    km = cluster.kmean(n_clusters=k, random_state=42).fit(wh)
+    cent, labels, n_iter, inertia = oracle.kmeans_fit(wh, k, 42)
+    assert np.array_equal(km.labels_, labels)                     # bit-exact assignments
+    assert np.array_equal(km.cluster_centers_, cent)              # bit-exact centroids (integer sums)
+    assert km.n_iter_ == n_iter and abs(km.inertia_ - inertia) < 1e-9
+    assert np.array_equal(km.predict(wh), labels)
+
+
+def test_kmeans_sharded_equals_single(va, oracle):
+    """fake all-reduce: shards stepped one after another on one device, integer partial sums added."""
+    from vision_amd import ops
+    wh = wl.anchor_wh(4, 100001)
+    k = 5
+    cent0 = oracle.kmeans_init(wh, k, 42)
+    x = torch.from_numpy(wh).cuda()
+    cent = torch.from_numpy(cent0).cuda()
+    labels = torch.full((wh.shape[0],), 255, dtype=torch.uint8, device="cuda")
+    acc = torch.zeros(17, dtype=torch.int64, device="cuda")
+    ops.kmeans_step(x, cent, labels, acc)
+    total = torch.zeros_like(acc)
+    lab2 = torch.full((wh.shape[0],), 255, dtype=torch.uint8, device="cuda")
+    bounds = [0, 30000, 30001, 77777, 100001]
+    for a, b in zip(bounds[:-1], bounds[1:]):
+        part = torch.zeros_like(acc)
+        ops.kmeans_step(x[a:b], cent, lab2[a:b], part)
+        total += part
+    assert torch.equal(total, acc) and torch.equal(labels, lab2)
+    want = oracle.kmeans_step(wh, cent0, np.full(wh.shape[0], 255, np.uint8))
+    assert np.array_equal(acc.cpu().numpy(), want)

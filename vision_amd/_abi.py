@@ -1,0 +1,136 @@
+"""ctypes binding of libdetgeom.so (include/detgeom.h) + device plumbing.
+
+PyTorch is used only for device memory, streams and (elsewhere) torch.distributed.
+There is NO CPU fallback: if the library is missing, or no ROCm device is visible,
+every product call raises (vision_amd never imports oracle/).
+"""
+import ctypes as C
+import os
+import threading
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdetgeom.so")
+
+OK, EINVAL, EEMPTYROI, ENOMEM, EHIP = 0, -1, -2, -3, -4
+POOL_AVG, POOL_MAX = 0, 1
+
+_vp, _i64, _i32, _f32, _f64, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/detgeom.h declares
+SIGNATURES = {
+    "dg_version": (C.c_char_p, []),
+    "dg_last_error": (C.c_int, [C.c_char_p, _sz]),
+    "dg_iou_elementwise_f32": (C.c_int, [_vp, _vp, _i64, _f32, _vp, _vp]),
+    "dg_iou_elementwise_f64": (C.c_int, [_vp, _vp, _i64, _f64, _vp, _vp]),
+    "dg_iou_pairwise_f32": (C.c_int, [_vp, _i64, _vp, _i64, _f32, _vp, _vp]),
+    "dg_iou_rois_vs_gt_f64": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
+    "dg_nms_workspace_bytes": (_sz, [_i64, _i64]),
+    "dg_nms_batched_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _f32, C.c_int, _vp, _vp, _vp, _sz, _vp]),
+    "dg_nms_phase_sort": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _sz, _vp]),
+    "dg_nms_phase_mask": (C.c_int, [_vp, _i64, _i64, _f32, _vp, _sz, _vp]),
+    "dg_nms_phase_reduce": (C.c_int, [_vp, _i64, _i64, C.c_int, _vp, _vp, _vp, _sz, _vp]),
+    "dg_yolo1_decode_f32": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dg_yolo2_get_point_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    "dg_yolo2_decode_cells_f32": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    "dg_yolo2_decode_anchor_f32": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),
+    "dg_roi_windows": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
+    "dg_nchw_to_nhwc_f32": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp]),
+    "dg_roipool_fwd_f32": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, C.c_int, _vp, _vp, _vp]),
+    "dg_roipool_bwd_workspace_bytes": (_sz, [_i64, _i64]),
+    "dg_roipool_bwd_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, C.c_int, _vp, _vp, _sz, _vp]),
+    "dg_kmeans_workspace_bytes": (_sz, [_i64, _i64]),
+    "dg_kmeans_iou_step": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "dg_kmeans_update": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp]),
+    "dg_kmeans_labels_i32": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "dg_rcnn_calcul_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
+    "dg_rcnn_decode_f32": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, _vp]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class DetGeomError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libdetgeom.so (after torch, so the process keeps a single HIP runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise DetGeomError(
+                    f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                    "(or make -C vision_amd/csrc). There is no CPU fallback.")
+            lib = C.CDLL(LIB_PATH)
+            for name, (res, args) in SIGNATURES.items():
+                fn = getattr(lib, name)          # AttributeError if a declared symbol is not exported
+                fn.restype, fn.argtypes = res, args
+            _lib = lib
+    return _lib
+
+
+def last_error():
+    buf = C.create_string_buffer(512)
+    load().dg_last_error(buf, 512)
+    return buf.value.decode(errors="replace")
+
+
+def check(status, exc=None):
+    if status == OK:
+        return
+    msg = last_error()
+    if status == EINVAL:
+        raise (exc or ValueError)(msg)
+    if status == ENOMEM:
+        raise MemoryError(msg)
+    raise DetGeomError(f"libdetgeom status {status}: {msg}")
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise DetGeomError("vision_amd needs a ROCm device (MI355X); there is no CPU fallback")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def device_of(*tensors):
+    """Device the kernels run on: the device of the first GPU tensor, else the current GPU."""
+    for t in tensors:
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            return t.device
+    return require_gpu()
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+# per-device scratch, grown on demand (the C ABI allocates nothing)
+_ws = {}
+
+
+def workspace(device, nbytes):
+    key = (device.type, device.index)
+    buf = _ws.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = None
+        _ws.pop(key, None)
+        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        _ws[key] = buf
+    return buf
+
+
+def to_dev(x, dtype, device):
+    """Host arrays / CPU tensors are copied in; GPU tensors are used in place (contiguous)."""
+    if not isinstance(x, torch.Tensor):
+        x = torch.as_tensor(x)
+    return x.to(device=device, dtype=dtype).contiguous()

@@ -1,0 +1,422 @@
+// nms.hip — greedy bitmask NMS for gfx950 (wave64).
+// Reference: nms(out_box,out_score,threshold), yolo/yolo_v1/yolo.py:188-203, whose IoU row is
+// get_iou (yolo/yolo_v1/modules.py:73-98).  Three phases, all batched over images:
+//   sort   : 64-bit keys (~orderable(score) << 32 | index), bitonic in LDS (global passes for
+//            segments > 4096), then a gather that lays the sorted boxes out as SoA planes
+//            x1[],y1[],x2[],y2[],area[] so the mask phase reads coalesced dwords;
+//   mask   : for sorted rows i and columns j>i, bit (i,j) = !(iou(i,j) < thr).  One lane owns one
+//            column, the row box is an LDS broadcast and the 64-bit word of a row is the wave's
+//            v_cmp result (__ballot); words go out row-major [i][W] in 128-byte pieces;
+//   reduce : one workgroup per image walks the 64-row blocks in order; the intra-block chain is
+//            resolved from the diagonal word in scalar registers (readlane), the kept rows are
+//            OR-ed into per-thread `removed` words.  Implements the reference's `numel()>1`
+//            quirk exactly.
+#include "common.hpp"
+
+#define SORT_CHUNK 4096  // elements sorted inside LDS (32 KiB of keys)
+
+struct NmsWs {
+    int64_t Np, W, Np2;
+    u64 *keys;
+    float *x1, *y1, *x2, *y2, *area;
+    int32_t *order;
+    u64 *mask;
+    size_t total;
+};
+
+static inline int64_t next_pow2(int64_t v) { int64_t p = 64; while (p < v) p <<= 1; return p; }
+
+static NmsWs nms_layout(int64_t batch, int64_t nmax, void *base)
+{
+    NmsWs w;
+    w.Np = dg_round_up(nmax > 0 ? nmax : 1, 64);
+    w.W = w.Np / 64;
+    w.Np2 = next_pow2(nmax);
+    char *p = (char *)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *r = p + off; off += (bytes + 255) & ~(size_t)255; return r; };
+    w.keys = (u64 *)take((size_t)batch * w.Np2 * 8);
+    w.x1 = (float *)take((size_t)batch * w.Np * 4);
+    w.y1 = (float *)take((size_t)batch * w.Np * 4);
+    w.x2 = (float *)take((size_t)batch * w.Np * 4);
+    w.y2 = (float *)take((size_t)batch * w.Np * 4);
+    w.area = (float *)take((size_t)batch * w.Np * 4);
+    w.order = (int32_t *)take((size_t)batch * w.Np * 4);
+    w.mask = (u64 *)take((size_t)batch * w.Np * w.W * 8);
+    w.total = off;
+    return w;
+}
+
+// descending score <=> ascending key; ties -> lower index first; NaN sorts first (as torch)
+__device__ __forceinline__ u64 make_key(float score, u32 idx)
+{
+    u32 u = __float_as_uint(score);
+    if (score != score) u = 0x7fffffffu;            // canonical +NaN: above +inf
+    u32 ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((u64)(~ord) << 32) | idx;
+}
+
+__device__ __forceinline__ void gather_sorted(const float4 *__restrict__ boxes, u64 key, bool valid, int64_t p,
+                                              float *x1, float *y1, float *x2, float *y2, float *area, int32_t *order)
+{
+    float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+    int32_t idx = 0;
+    if (valid) { idx = (int32_t)(u32)key; b = boxes[idx]; }
+    x1[p] = b.x; y1[p] = b.y; x2[p] = b.z; y2[p] = b.w;
+    area[p] = dg_area(b.x, b.y, b.z, b.w);
+    order[p] = idx;
+}
+
+// ---------------------------------------------------------------- sort, segments <= 4096
+template <int NP2, int T>
+__global__ __launch_bounds__(T) void k_nms_sort_small(const float4 *__restrict__ boxes, const float *__restrict__ scores,
+                                                      const int32_t *__restrict__ counts, int64_t nmax, int64_t Np,
+                                                      float *x1, float *y1, float *x2, float *y2, float *area, int32_t *order)
+{
+    __shared__ u64 keys[NP2];
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const int n = counts ? counts[img] : (int)nmax;
+    boxes += (int64_t)img * nmax;
+    scores += (int64_t)img * nmax;
+    for (int i = tid; i < NP2; i += T) keys[i] = (i < n) ? make_key(scores[i], (u32)i) : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= NP2; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < NP2 / 2; t += T) {
+                int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                int l = i | j;
+                u64 a = keys[i], b = keys[l];
+                bool asc = (i & k) == 0;
+                if ((a > b) == asc) { keys[i] = b; keys[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    const int64_t o = (int64_t)img * Np;
+    for (int p = tid; p < (int)Np; p += T)
+        gather_sorted(boxes, p < NP2 ? keys[p] : 0, p < n, o + p, x1, y1, x2, y2, area, order);
+}
+
+// ---------------------------------------------------------------- sort, long segments (global bitonic)
+__global__ __launch_bounds__(256) void k_nms_make_keys(const float *__restrict__ scores, const int32_t *__restrict__ counts,
+                                                       int64_t nmax, int64_t Np2, u64 *__restrict__ keys)
+{
+    const int img = blockIdx.y;
+    const int n = counts ? counts[img] : (int)nmax;
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < Np2) keys[(int64_t)img * Np2 + i] = (i < n) ? make_key(scores[(int64_t)img * nmax + i], (u32)i) : ~0ull;
+}
+
+// sorts/merges one SORT_CHUNK in LDS: stages k = kfirst..klast, and inside stage kfirst only j <= jfirst
+__global__ __launch_bounds__(1024) void k_bitonic_lds(u64 *__restrict__ keys, int64_t Np2, int64_t kfirst, int64_t klast, int jfirst)
+{
+    __shared__ u64 s[SORT_CHUNK];
+    const int tid = threadIdx.x;
+    const int64_t base = (int64_t)blockIdx.x * SORT_CHUNK;
+    u64 *g = keys + (int64_t)blockIdx.y * Np2 + base;
+    for (int i = tid; i < SORT_CHUNK; i += 1024) s[i] = g[i];
+    __syncthreads();
+    for (int64_t k = kfirst; k <= klast; k <<= 1) {
+        int j0 = (k == kfirst) ? jfirst : (int)(k >> 1);
+        for (int j = j0; j > 0; j >>= 1) {
+            for (int t = tid; t < SORT_CHUNK / 2; t += 1024) {
+                int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+                int l = i | j;
+                u64 a = s[i], b = s[l];
+                bool asc = ((base + i) & k) == 0;
+                if ((a > b) == asc) { s[i] = b; s[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < SORT_CHUNK; i += 1024) g[i] = s[i];
+}
+
+__global__ __launch_bounds__(256) void k_bitonic_global(u64 *__restrict__ keys, int64_t Np2, int64_t k, int64_t j)
+{
+    int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (t >= Np2 / 2) return;
+    u64 *g = keys + (int64_t)blockIdx.y * Np2;
+    int64_t i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+    int64_t l = i | j;
+    u64 a = g[i], b = g[l];
+    bool asc = (i & k) == 0;
+    if ((a > b) == asc) { g[i] = b; g[l] = a; }
+}
+
+__global__ __launch_bounds__(256) void k_nms_gather(const float4 *__restrict__ boxes, const u64 *__restrict__ keys,
+                                                    const int32_t *__restrict__ counts, int64_t nmax, int64_t Np, int64_t Np2,
+                                                    float *x1, float *y1, float *x2, float *y2, float *area, int32_t *order)
+{
+    const int img = blockIdx.y;
+    const int n = counts ? counts[img] : (int)nmax;
+    int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= Np) return;
+    gather_sorted(boxes + (int64_t)img * nmax, keys[(int64_t)img * Np2 + p], p < n, (int64_t)img * Np + p, x1, y1, x2, y2, area, order);
+}
+
+// ---------------------------------------------------------------- mask
+// grid: x = column tile (16 words = 1024 columns), y = 64-row block, z = image.  256 threads.
+#define MASK_WORDS 16
+__global__ __launch_bounds__(256) void k_nms_mask(const float *__restrict__ sx1, const float *__restrict__ sy1,
+                                                  const float *__restrict__ sx2, const float *__restrict__ sy2,
+                                                  const float *__restrict__ sarea, const int32_t *__restrict__ counts,
+                                                  int64_t nmax, int64_t Np, int64_t W, float thr, u64 *__restrict__ mask)
+{
+    __shared__ float4 rbox[64];
+    __shared__ float rarea[64];
+    __shared__ u64 tile[64][MASK_WORDS + 1];
+    const int img = blockIdx.z;
+    const int n = counts ? counts[img] : (int)nmax;
+    const int ib = blockIdx.y;
+    const int jb0 = blockIdx.x * MASK_WORDS;
+    if (ib * 64 >= n || jb0 * 64 >= n || jb0 + MASK_WORDS <= ib) return;   // below the diagonal / outside
+    const int64_t o = (int64_t)img * Np;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 64) {
+        int64_t i = o + ib * 64 + tid;
+        rbox[tid] = make_float4(sx1[i], sy1[i], sx2[i], sy2[i]);
+        rarea[tid] = sarea[i];
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int q = 0; q < MASK_WORDS / 4; ++q) {
+        const int wi = wave + 4 * q;
+        const int jb = jb0 + wi;
+        u64 myword = 0;
+        if (jb >= ib && jb < W && jb * 64 < n) {          // wave-uniform
+            const int64_t j = o + (int64_t)jb * 64 + lane;
+            const float cx1 = sx1[j], cy1 = sy1[j], cx2 = sx2[j], cy2 = sy2[j], ca = sarea[j];
+#pragma unroll 8
+            for (int r = 0; r < 64; ++r) {
+                float4 p = rbox[r];
+                float iou = dg_iou(p.x, p.y, p.z, p.w, rarea[r], cx1, cy1, cx2, cy2, ca, 1e-7f);
+                u64 bal = __ballot(!(iou < thr));         // yolo.py:201 keeps iou < thr; NaN is suppressed
+                if (lane == r) myword = bal;
+            }
+            if (jb == ib) myword &= ~((2ull << lane) - 1ull);   // only j > i
+        }
+        tile[lane][wi] = myword;
+    }
+    __syncthreads();
+    // 64 rows x 16 words out, 128 contiguous bytes per row
+    u64 *mo = mask + (o + (int64_t)ib * 64) * W + jb0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        int row = (tid >> 4) + 16 * p, word = tid & 15;
+        if (jb0 + word < W) mo[(int64_t)row * W + word] = tile[row][word];
+    }
+}
+
+// ---------------------------------------------------------------- reduce
+__device__ __forceinline__ u64 uniform64(u64 v)
+{
+    u32 lo = __builtin_amdgcn_readfirstlane((u32)v), hi = __builtin_amdgcn_readfirstlane((u32)(v >> 32));
+    return ((u64)hi << 32) | lo;
+}
+__device__ __forceinline__ u64 readlane64(u64 v, int l)
+{
+    u32 lo = __builtin_amdgcn_readlane((u32)v, l), hi = __builtin_amdgcn_readlane((u32)(v >> 32), l);
+    return ((u64)hi << 32) | lo;
+}
+
+template <int T, int WPT>
+__global__ __launch_bounds__(T) void k_nms_reduce(const u64 *__restrict__ mask, const int32_t *__restrict__ order,
+                                                  const int32_t *__restrict__ counts, int64_t nmax, int64_t Np, int64_t W,
+                                                  int quirk, int64_t *__restrict__ keep, int32_t *__restrict__ keep_count)
+{
+    __shared__ u64 s_remv, s_kept, s_curb;
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const int n = counts ? counts[img] : (int)nmax;
+    mask += (int64_t)img * Np * W;
+    order += (int64_t)img * Np;
+    keep += (int64_t)img * nmax;
+
+    u64 remv[WPT], prev[WPT];
+#pragma unroll
+    for (int q = 0; q < WPT; ++q) {
+        int64_t base = ((int64_t)tid + (int64_t)q * T) * 64;
+        remv[q] = (base >= n) ? ~0ull : ((n - base >= 64) ? 0ull : (~0ull << (n - base)));
+        prev[q] = remv[q];
+    }
+    int total = 0, last_ib = -1, last_r = 0;
+    u64 last_curb = 0;
+    const int nb = (n + 63) >> 6;
+    for (int ib = 0; ib < nb; ++ib) {
+        {   // owner of word ib publishes it
+            const int own = ib % T, oq = ib / T;
+#pragma unroll
+            for (int q = 0; q < WPT; ++q)
+                if (q == oq && tid == own) s_remv = remv[q];
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const u64 diag = mask[((int64_t)ib * 64 + tid) * W + ib];
+            u64 cur = uniform64(s_remv), kept = 0, curb = cur;
+            u64 alive = ~cur;
+            while (alive) {
+                int r = __builtin_ctzll(alive);
+                kept |= 1ull << r;
+                curb = cur;
+                cur |= readlane64(diag, r);
+                alive = ~cur & ~((2ull << r) - 1ull);
+            }
+            if ((kept >> tid) & 1ull) {
+                int pos = total + __builtin_popcountll(kept & ((1ull << tid) - 1ull));
+                keep[pos] = (int64_t)order[ib * 64 + tid];
+            }
+            if (tid == 0) { s_kept = kept; s_curb = curb; }
+        }
+        __syncthreads();
+        const u64 kept = uniform64(s_kept);
+        if (kept) {
+            const int rl = 63 - __builtin_clzll(kept);
+            last_ib = ib; last_r = rl; last_curb = uniform64(s_curb);
+            total += __builtin_popcountll(kept);
+            const u64 others = kept & ~(1ull << rl);
+#pragma unroll
+            for (int q = 0; q < WPT; ++q) {
+                const int64_t w = (int64_t)tid + (int64_t)q * T;
+                if (w > ib && w < W) {
+                    const u64 *rowbase = mask + (int64_t)ib * 64 * W + w;
+                    u64 acc = 0, k = others;
+                    while (k) {
+                        u64 v0, v1 = 0, v2 = 0, v3 = 0;
+                        int r = __builtin_ctzll(k); k &= k - 1; v0 = rowbase[(int64_t)r * W];
+                        if (k) { r = __builtin_ctzll(k); k &= k - 1; v1 = rowbase[(int64_t)r * W]; }
+                        if (k) { r = __builtin_ctzll(k); k &= k - 1; v2 = rowbase[(int64_t)r * W]; }
+                        if (k) { r = __builtin_ctzll(k); k &= k - 1; v3 = rowbase[(int64_t)r * W]; }
+                        acc |= (v0 | v1) | (v2 | v3);
+                    }
+                    u64 vl = rowbase[(int64_t)rl * W];
+                    remv[q] |= acc;
+                    prev[q] = remv[q];
+                    remv[q] |= vl;
+                }
+            }
+        }
+    }
+    if (quirk && total > 0) {
+        // yolo.py:196 `while ids_sorted.numel()>1`: the last kept box km is dropped iff nothing ranked
+        // below it was still alive when it became the head, i.e. before its own row was applied.
+        int surv = 0;
+        const u64 above = (last_r == 63) ? 0ull : (~0ull << (last_r + 1));
+        if (tid == 0) surv = ((~last_curb) & above) != 0;
+#pragma unroll
+        for (int q = 0; q < WPT; ++q) {
+            const int64_t w = (int64_t)tid + (int64_t)q * T;
+            if (w > last_ib && w < W) surv |= (~prev[q]) != 0ull;
+        }
+        surv = __syncthreads_or(surv);
+        if (!surv) total -= 1;
+    }
+    if (tid == 0) keep_count[img] = total;
+}
+
+// ---------------------------------------------------------------- host
+extern "C" size_t dg_nms_workspace_bytes(int64_t batch, int64_t nmax)
+{
+    if (batch <= 0 || nmax < 0) return 0;
+    return nms_layout(batch, nmax, nullptr).total;
+}
+
+static int nms_check(const char *fn, int64_t batch, int64_t nmax, void *ws, size_t ws_bytes, NmsWs *out)
+{
+    DG_REQUIRE(batch >= 0 && nmax >= 0, "%s: negative size", fn);
+    DG_REQUIRE(nmax <= (1 << 20), "%s: nmax %lld > 1048576 unsupported", fn, (long long)nmax);
+    DG_REQUIRE(batch <= 65535, "%s: batch > 65535", fn);
+    if (batch == 0 || nmax == 0) { out->total = 0; return DG_OK; }
+    DG_REQUIRE(ws && (((uintptr_t)ws) & 255) == 0, "%s: workspace null or not 256-byte aligned", fn);
+    *out = nms_layout(batch, nmax, ws);
+    if (ws_bytes < out->total) { dg_set_error("%s: workspace %zu < %zu bytes", fn, ws_bytes, out->total); return DG_ENOMEM; }
+    return DG_OK;
+}
+
+template <int NP2>
+static void launch_sort_small(const NmsWs &w, const float *boxes, const float *scores, const int32_t *counts,
+                              int64_t batch, int64_t nmax, hipStream_t st)
+{
+    constexpr int T = (NP2 / 2 > 1024) ? 1024 : (NP2 / 2 < 64 ? 64 : NP2 / 2);
+    hipLaunchKernelGGL((k_nms_sort_small<NP2, T>), dim3((unsigned)batch), dim3(T), 0, st, (const float4 *)boxes, scores, counts,
+                       nmax, w.Np, w.x1, w.y1, w.x2, w.y2, w.area, w.order);
+}
+
+extern "C" int dg_nms_phase_sort(const float *boxes, const float *scores, const int32_t *counts, int64_t batch, int64_t nmax,
+                                 void *ws, size_t ws_bytes, dg_stream_t s)
+{
+    NmsWs w;
+    int rc = nms_check("nms_sort", batch, nmax, ws, ws_bytes, &w);
+    if (rc || batch == 0 || nmax == 0) return rc;
+    DG_REQUIRE(boxes && scores, "nms_sort: null pointer");
+    DG_REQUIRE((((uintptr_t)boxes) & 15) == 0, "nms_sort: boxes must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)s;
+    switch (w.Np2) {
+    case 64: launch_sort_small<64>(w, boxes, scores, counts, batch, nmax, st); break;
+    case 128: launch_sort_small<128>(w, boxes, scores, counts, batch, nmax, st); break;
+    case 256: launch_sort_small<256>(w, boxes, scores, counts, batch, nmax, st); break;
+    case 512: launch_sort_small<512>(w, boxes, scores, counts, batch, nmax, st); break;
+    case 1024: launch_sort_small<1024>(w, boxes, scores, counts, batch, nmax, st); break;
+    case 2048: launch_sort_small<2048>(w, boxes, scores, counts, batch, nmax, st); break;
+    case 4096: launch_sort_small<4096>(w, boxes, scores, counts, batch, nmax, st); break;
+    default: {
+        const int64_t Np2 = w.Np2;
+        hipLaunchKernelGGL(k_nms_make_keys, dim3((unsigned)(Np2 / 256), (unsigned)batch), dim3(256), 0, st, scores, counts, nmax, Np2, w.keys);
+        dim3 gl((unsigned)(Np2 / SORT_CHUNK), (unsigned)batch), gg((unsigned)(Np2 / 2 / 256), (unsigned)batch);
+        hipLaunchKernelGGL(k_bitonic_lds, gl, dim3(1024), 0, st, w.keys, Np2, (int64_t)2, (int64_t)SORT_CHUNK, 1);
+        for (int64_t k = 2 * SORT_CHUNK; k <= Np2; k <<= 1) {
+            for (int64_t j = k >> 1; j >= SORT_CHUNK; j >>= 1)
+                hipLaunchKernelGGL(k_bitonic_global, gg, dim3(256), 0, st, w.keys, Np2, k, j);
+            hipLaunchKernelGGL(k_bitonic_lds, gl, dim3(1024), 0, st, w.keys, Np2, k, k, SORT_CHUNK / 2);
+        }
+        hipLaunchKernelGGL(k_nms_gather, dim3((unsigned)dg_cdiv(w.Np, 256), (unsigned)batch), dim3(256), 0, st, (const float4 *)boxes,
+                           w.keys, counts, nmax, w.Np, Np2, w.x1, w.y1, w.x2, w.y2, w.area, w.order);
+    }
+    }
+    DG_CHECK_LAUNCH("nms sort");
+    return DG_OK;
+}
+
+extern "C" int dg_nms_phase_mask(const int32_t *counts, int64_t batch, int64_t nmax, float threshold,
+                                 void *ws, size_t ws_bytes, dg_stream_t s)
+{
+    NmsWs w;
+    int rc = nms_check("nms_mask", batch, nmax, ws, ws_bytes, &w);
+    if (rc || batch == 0 || nmax == 0) return rc;
+    dim3 grid((unsigned)dg_cdiv(w.W, MASK_WORDS), (unsigned)w.W, (unsigned)batch);
+    hipLaunchKernelGGL(k_nms_mask, grid, dim3(256), 0, (hipStream_t)s, w.x1, w.y1, w.x2, w.y2, w.area, counts, nmax, w.Np, w.W,
+                       threshold, w.mask);
+    DG_CHECK_LAUNCH("k_nms_mask");
+    return DG_OK;
+}
+
+extern "C" int dg_nms_phase_reduce(const int32_t *counts, int64_t batch, int64_t nmax, int quirk_drop_last,
+                                   int64_t *keep, int32_t *keep_count, void *ws, size_t ws_bytes, dg_stream_t s)
+{
+    NmsWs w;
+    int rc = nms_check("nms_reduce", batch, nmax, ws, ws_bytes, &w);
+    if (rc || batch == 0) return rc;
+    DG_REQUIRE(keep_count, "nms_reduce: null keep_count");
+    hipStream_t st = (hipStream_t)s;
+    if (nmax == 0) { hipError_t e = hipMemsetAsync(keep_count, 0, (size_t)batch * 4, st); return e == hipSuccess ? DG_OK : DG_EHIP; }
+    DG_REQUIRE(keep, "nms_reduce: null keep");
+#define RED(T, WPT) hipLaunchKernelGGL((k_nms_reduce<T, WPT>), dim3((unsigned)batch), dim3(T), 0, st, w.mask, w.order, counts, \
+                                       nmax, w.Np, w.W, quirk_drop_last, keep, keep_count)
+    if (w.W <= 64) RED(64, 1);
+    else if (w.W <= 1024) RED(1024, 1);
+    else if (w.W <= 4096) RED(1024, 4);
+    else RED(1024, 16);
+#undef RED
+    DG_CHECK_LAUNCH("k_nms_reduce");
+    return DG_OK;
+}
+
+extern "C" int dg_nms_batched_f32(const float *boxes, const float *scores, const int32_t *counts, int64_t batch, int64_t nmax,
+                                  float threshold, int quirk_drop_last, int64_t *keep, int32_t *keep_count,
+                                  void *ws, size_t ws_bytes, dg_stream_t s)
+{
+    int rc = dg_nms_phase_sort(boxes, scores, counts, batch, nmax, ws, ws_bytes, s);
+    if (rc) return rc;
+    rc = dg_nms_phase_mask(counts, batch, nmax, threshold, ws, ws_bytes, s);
+    if (rc) return rc;
+    return dg_nms_phase_reduce(counts, batch, nmax, quirk_drop_last, keep, keep_count, ws, ws_bytes, s);
+}

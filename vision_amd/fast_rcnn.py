@@ -1,0 +1,76 @@
+"""Drop-ins for rcnn/fast_rcnn.py.
+
+  slowroipool(output_size).foward(img, roi_ary, roi_idx)   rcnn/fast_rcnn.py:351-377
+  nms(rects, scores) -> (rect, score)                      rcnn/fast_rcnn.py:590-610
+
+As written the reference pools with AdaptiveAvgPool2d stored in a field called `maxpool`
+(:354) and never defines backward (autograd).  `mode="max"` (default, what north_star asks
+for) is the same module with AdaptiveMaxPool2d substituted and also yields the argmax used by
+the backward scatter; `mode="avg"` is the literal reference.
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+
+class _RoIPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, win, mode):
+        out, argmax = ops.roipool_forward(img, win, mode)
+        ctx.mode, ctx.img_shape = mode, tuple(img.shape)
+        ctx.save_for_backward(win, argmax if argmax is not None else win)
+        ctx.argmax = argmax
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        win, arg = ctx.saved_tensors
+        g = ops.roipool_backward(grad_out.contiguous(), arg if ctx.mode == "max" else None, win, ctx.img_shape, ctx.mode)
+        return g, None, None
+
+
+class slowroipool(torch.nn.Module):
+    def __init__(self, output_size, mode="max"):
+        super().__init__()
+        size = tuple(output_size) if isinstance(output_size, (tuple, list)) else (output_size, output_size)
+        if size != (7, 7):
+            raise ValueError("slowroipool: only output_size (7,7) is built")
+        if mode not in ("max", "avg"):
+            raise ValueError("mode must be 'max' or 'avg'")
+        self.size = size
+        self.mode = mode
+        self.argmax = None            # (n,C,7,7) int32 of the last max-mode forward (flat y*W+x in the map)
+
+    def foward(self, img, roi_ary, roi_idx):          # sic: the reference's spelling (:357)
+        was_cpu = not img.is_cuda
+        dev = ops._abi.device_of(img)
+        x = img.to(device=dev, dtype=torch.float32)
+        B, C, H, W = x.shape
+        win, status = ops.roi_windows(np.asarray(roi_ary, np.float64) if not isinstance(roi_ary, torch.Tensor) else roi_ary,
+                                      np.asarray(roi_idx, np.int64) if not isinstance(roi_idx, torch.Tensor) else roi_idx,
+                                      B, H, W, dev)
+        st = int(status.item())
+        if st & 1:
+            raise RuntimeError("slowroipool: a RoI crop is empty (x2<=x1 or y2<=y1 after floor/ceil)")
+        if st & 2:
+            raise IndexError("slowroipool: roi_idx out of range")
+        if x.requires_grad:
+            out = _RoIPoolFn.apply(x, win, self.mode)
+        else:
+            out, self.argmax = ops.roipool_forward(x, win, self.mode)
+        return out.cpu() if was_cpu else out
+
+    forward = foward
+
+
+def nms(rects, scores):
+    """The reference's function of this name does no suppression and returns the top-score rect
+    (:601-610); a greedy NMS's first keep is that same rect, so the GPU path is output-compatible."""
+    rects_a = np.array(rects)
+    scores_a = np.array(scores)
+    boxes = torch.as_tensor(rects_a.astype(np.float32)).reshape(1, -1, 4)
+    sc = torch.as_tensor(scores_a.astype(np.float32)).reshape(1, -1)
+    keep, cnt = ops.nms_batched(boxes, sc, None, 0.7, quirk_drop_last=False)
+    top = int(keep[0, 0].item())
+    return rects_a[top], scores_a[top]

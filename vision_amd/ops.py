@@ -1,0 +1,183 @@
+"""Tensor-level front end of the HIP kernels: GPU tensors in, GPU tensors out, async on the
+current stream.  The reference-named drop-ins (yolo_v1.py, yolo_v2.py, rcnn_utils.py,
+fast_rcnn.py, cluster.py) are thin layers over these."""
+import torch
+
+from . import _abi
+from ._abi import check, load, ptr, stream_ptr, workspace
+
+
+def _f32c(t, dev):
+    return _abi.to_dev(t, torch.float32, dev)
+
+
+# ------------------------------------------------------------------ IoU
+def iou_elementwise(bb1, bb2, eps=1e-7):
+    dev = _abi.device_of(bb1, bb2)
+    f64 = isinstance(bb1, torch.Tensor) and bb1.dtype == torch.float64
+    dt = torch.float64 if f64 else torch.float32
+    a, b = _abi.to_dev(bb1, dt, dev).reshape(-1, 4), _abi.to_dev(bb2, dt, dev).reshape(-1, 4)
+    if a.shape != b.shape:
+        raise ValueError(f"get_iou: shapes differ {tuple(a.shape)} vs {tuple(b.shape)}")
+    out = torch.empty(a.shape[0], dtype=dt, device=dev)
+    fn = load().dg_iou_elementwise_f64 if f64 else load().dg_iou_elementwise_f32
+    with torch.cuda.device(dev):
+        check(fn(ptr(a), ptr(b), a.shape[0], eps, ptr(out), stream_ptr(dev)))
+    return out
+
+
+def iou_pairwise(a, b, eps=1e-7, out=None):
+    dev = _abi.device_of(a, b)
+    a, b = _f32c(a, dev).reshape(-1, 4), _f32c(b, dev).reshape(-1, 4)
+    if out is None:
+        out = torch.empty((a.shape[0], b.shape[0]), dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        check(load().dg_iou_pairwise_f32(ptr(a), a.shape[0], ptr(b), b.shape[0], eps, ptr(out), stream_ptr(dev)))
+    return out
+
+
+def iou_rois_vs_gt(rois, grt):
+    """float64 IoU of n xyxy rois against one box + per-roi assert flags (rcnn/utils.py:50-67)."""
+    dev = _abi.device_of(rois, grt)
+    r = _abi.to_dev(rois, torch.float64, dev).reshape(-1, 4)
+    g = _abi.to_dev(grt, torch.float64, dev).reshape(4)
+    out = torch.empty(r.shape[0], dtype=torch.float64, device=dev)
+    flags = torch.empty(r.shape[0], dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(load().dg_iou_rois_vs_gt_f64(ptr(r), ptr(g), r.shape[0], ptr(out), ptr(flags), stream_ptr(dev)))
+    return out, flags
+
+
+# ------------------------------------------------------------------ NMS
+def nms_workspace(dev, batch, nmax):
+    nbytes = load().dg_nms_workspace_bytes(batch, nmax)
+    return workspace(dev, nbytes), nbytes
+
+
+def nms_batched(boxes, scores, counts=None, threshold=0.1, quirk_drop_last=True, keep=None, keep_count=None):
+    """boxes (B,N,4) fp32, scores (B,N), counts (B) int32 or None -> keep (B,N) int64, keep_count (B) int32."""
+    dev = _abi.device_of(boxes, scores)
+    boxes, scores = _f32c(boxes, dev), _f32c(scores, dev)
+    B, N = scores.shape
+    if boxes.shape != (B, N, 4):
+        raise ValueError("nms_batched: boxes must be (B,N,4) matching scores (B,N)")
+    if counts is not None:
+        counts = _abi.to_dev(counts, torch.int32, dev)
+    if keep is None:
+        keep = torch.empty((B, N), dtype=torch.int64, device=dev)
+    if keep_count is None:
+        keep_count = torch.empty((B,), dtype=torch.int32, device=dev)
+    ws, nbytes = nms_workspace(dev, B, N)
+    with torch.cuda.device(dev):
+        check(load().dg_nms_batched_f32(ptr(boxes), ptr(scores), ptr(counts), B, N, float(threshold), int(quirk_drop_last),
+                                        ptr(keep), ptr(keep_count), ptr(ws), nbytes, stream_ptr(dev)))
+    return keep, keep_count
+
+
+# ------------------------------------------------------------------ YOLOv1 decode
+def yolo1_decode_batched(output, target=None, conf_threshold=0.2, prob_threshold=0.1):
+    dev = _abi.device_of(output, target)
+    o = _f32c(output, dev)
+    if o.dim() == 3:
+        o = o.unsqueeze(0)
+    B = o.shape[0]
+    if tuple(o.shape[1:3]) != (7, 7) or o.shape[3] < 11:
+        raise ValueError("decode: output must be (...,7,7,10+C)")
+    C_ = o.shape[3] - 10
+    t = None
+    if target is not None:
+        t = _f32c(target, dev).reshape(o.shape)
+    box = torch.empty((B, 98, 4), dtype=torch.float32, device=dev)
+    label = torch.empty((B, 98), dtype=torch.int64, device=dev)
+    conf = torch.empty((B, 98), dtype=torch.float32, device=dev)
+    score = torch.empty((B, 98), dtype=torch.float32, device=dev)
+    count = torch.empty((B,), dtype=torch.int32, device=dev)
+    tbox = torch.empty((B, 4), dtype=torch.float64, device=dev) if t is not None else None
+    tlabel = torch.empty((B,), dtype=torch.int64, device=dev) if t is not None else None
+    with torch.cuda.device(dev):
+        check(load().dg_yolo1_decode_f32(ptr(o), ptr(t), B, C_, float(conf_threshold), float(prob_threshold), ptr(box), ptr(label),
+                                         ptr(conf), ptr(score), ptr(count), ptr(tbox), ptr(tlabel), stream_ptr(dev)))
+    return box, label, conf, score, count, tbox, tlabel
+
+
+# ------------------------------------------------------------------ RoI pooling
+def roi_windows(rois, roi_idx, B, H, W, dev):
+    r = _abi.to_dev(rois, torch.float64, dev).reshape(-1, 4)
+    idx = _abi.to_dev(roi_idx, torch.int64, dev).reshape(-1)
+    if idx.shape[0] != r.shape[0]:
+        raise ValueError("roi_idx must have one entry per RoI")
+    win = torch.empty((r.shape[0], 5), dtype=torch.int32, device=dev)
+    status = torch.zeros((1,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(load().dg_roi_windows(ptr(r), ptr(idx), r.shape[0], B, H, W, ptr(win), ptr(status), stream_ptr(dev)))
+    return win, status
+
+
+def to_nhwc(img):
+    """(B,C,H,W) fp32 -> (B,H,W,C) staging copy; free if the tensor is already channels_last."""
+    B, C_, H, W = img.shape
+    if img.is_contiguous(memory_format=torch.channels_last) and not img.is_contiguous():
+        return img.permute(0, 2, 3, 1)             # same bytes, viewed NHWC
+    img = img.contiguous()
+    out = torch.empty((B, H, W, C_), dtype=torch.float32, device=img.device)
+    with torch.cuda.device(img.device):
+        check(load().dg_nchw_to_nhwc_f32(ptr(img), B, C_, H, W, ptr(out), stream_ptr(img.device)))
+    return out
+
+
+def roipool_forward(img, win, mode="max", P=7, out=None, argmax=None, nhwc=None):
+    dev = img.device
+    B, C_, H, W = img.shape
+    n = win.shape[0]
+    if nhwc is None:
+        nhwc = to_nhwc(img)
+    m = _abi.POOL_MAX if mode == "max" else _abi.POOL_AVG
+    if out is None:
+        out = torch.empty((n, C_, P, P), dtype=torch.float32, device=dev)
+    if m == _abi.POOL_MAX and argmax is None:
+        argmax = torch.empty((n, C_, P, P), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(load().dg_roipool_fwd_f32(ptr(nhwc), B, C_, H, W, ptr(win), n, P, m, ptr(out),
+                                        ptr(argmax) if m == _abi.POOL_MAX else None, stream_ptr(dev)))
+    return out, (argmax if m == _abi.POOL_MAX else None)
+
+
+def roipool_backward(grad_out, argmax, win, img_shape, mode="max", P=7, grad_in=None):
+    dev = grad_out.device
+    B, C_, H, W = img_shape
+    n = win.shape[0]
+    g = grad_out.contiguous()
+    if grad_in is None:
+        grad_in = torch.empty((B, C_, H, W), dtype=torch.float32, device=dev)
+    nbytes = load().dg_roipool_bwd_workspace_bytes(B, n)
+    ws = workspace(dev, nbytes)
+    m = _abi.POOL_MAX if mode == "max" else _abi.POOL_AVG
+    with torch.cuda.device(dev):
+        check(load().dg_roipool_bwd_f32(ptr(g), ptr(argmax), ptr(win), n, B, C_, H, W, P, m, ptr(grad_in), ptr(ws), nbytes,
+                                        stream_ptr(dev)))
+    return grad_in
+
+
+# ------------------------------------------------------------------ k-means
+def kmeans_step(wh, cent, labels, acc):
+    dev = wh.device
+    n, k = wh.shape[0], cent.shape[0]
+    nbytes = load().dg_kmeans_workspace_bytes(n, k)
+    ws = workspace(dev, nbytes)
+    with torch.cuda.device(dev):
+        check(load().dg_kmeans_iou_step(ptr(wh), n, ptr(cent), k, ptr(labels), ptr(acc), ptr(ws), nbytes, stream_ptr(dev)))
+    return acc
+
+
+def kmeans_update(acc, cent, history=None, slot=0):
+    dev = cent.device
+    with torch.cuda.device(dev):
+        check(load().dg_kmeans_update(ptr(acc), cent.shape[0], ptr(cent), ptr(history), slot, stream_ptr(dev)))
+    return cent
+
+
+def kmeans_labels_i32(labels_u8):
+    out = torch.empty(labels_u8.shape, dtype=torch.int32, device=labels_u8.device)
+    with torch.cuda.device(labels_u8.device):
+        check(load().dg_kmeans_labels_i32(ptr(labels_u8), labels_u8.numel(), ptr(out), stream_ptr(labels_u8.device)))
+    return out

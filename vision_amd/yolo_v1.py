@@ -1,0 +1,140 @@
+"""Drop-ins for the box geometry of yolo/yolo_v1 (same names, arguments and return types as the
+reference; the arithmetic runs in HIP kernels on the MI355X).
+
+  get_iou(bb1, bb2)                       yolo/yolo_v1/modules.py:73-98
+  Loss.get_iou(self, bb1, bb2)            yolo/yolo_v1/modules.py:208-228   (eps 1e-6)
+  decode(output, target, conf_threshold, prob_threshold)   yolo/yolo_v1/yolo.py:115-186
+  nms(out_box, out_score, threshold)      yolo/yolo_v1/yolo.py:188-203
+  evaluate_batch(...)                     yolo/yolo_v1/yolo.py:273-299 after the model call
+  ap(detects, targets, iou_threds)        yolo/yolo_v1/yolo.py:306-367
+
+Results come back on the device of the inputs (CPU tensors are copied to the GPU and back);
+nothing here computes on the CPU except the list bookkeeping the reference also does in Python.
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+
+def _back(t, like):
+    return t if (isinstance(like, torch.Tensor) and like.is_cuda) else t.cpu()
+
+
+def get_iou(bb1, bb2):
+    return _back(ops.iou_elementwise(bb1, bb2, 1e-7), bb1)
+
+
+class Loss:
+    """Only the geometry of the reference's Loss module (modules.py:198-228)."""
+
+    def __init__(self, num_bboxes=2, num_classes=5):
+        self.S = 7
+        self.num_bboxes = num_bboxes
+        self.num_classes = num_classes
+
+    def get_iou(self, bb1, bb2):
+        return _back(ops.iou_elementwise(bb1, bb2, 1e-6), bb1)
+
+
+def decode(output, target, conf_threshold=0.2, prob_threshold=0.1):
+    """One image.  Returns (out_box (M,4) f32, out_label (M,) i64, out_conf, out_score, bbox_target (4,) f64,
+    label_target int); when nothing passes, the first four are empty Python lists (yolo.py:184-186)."""
+    box, label, conf, score, count, tbox, tlabel = ops.yolo1_decode_batched(output, target, conf_threshold, prob_threshold)
+    m = int(count[0].item())
+    bbox_target = _back(tbox[0], output)
+    label_target = int(tlabel[0].item())
+    if m == 0:
+        return [], [], [], [], bbox_target, label_target
+    return (_back(box[0, :m], output), _back(label[0, :m], output), _back(conf[0, :m], output),
+            _back(score[0, :m], output), bbox_target, label_target)
+
+
+def nms(out_box, out_score, threshold=0.1):
+    """Class-agnostic greedy NMS, keep indices (int64) in descending-score order, including the
+    reference's quirk that the candidate left alone at the end is not kept."""
+    if len(out_box) == 0:
+        return torch.LongTensor([])
+    dev_in = out_box
+    boxes = torch.as_tensor(out_box)
+    scores = torch.as_tensor(out_score)
+    keep, cnt = ops.nms_batched(boxes.reshape(1, -1, 4), scores.reshape(1, -1), None, threshold, True)
+    k = int(cnt[0].item())
+    return _back(keep[0, :k], dev_in)
+
+
+def decode_nms_batched(output, target=None, conf_threshold=0.2, prob_threshold=0.1, nms_threshold=0.3):
+    """Fused path for a whole batch (config 2): decode -> batched NMS with no host round trip in between.
+    Returns device tensors (box, label, conf, score, count, keep, keep_count, tbox, tlabel)."""
+    box, label, conf, score, count, tbox, tlabel = ops.yolo1_decode_batched(output, target, conf_threshold, prob_threshold)
+    keep, kcnt = ops.nms_batched(box, score, count, nms_threshold, True)
+    return box, label, conf, score, count, keep, kcnt, tbox, tlabel
+
+
+def evaluate_batch(output, target, num_classes=5, prob_threshold=0.005, nms_threshold=0.3, detects=None, targets=None):
+    """yolo.py:273-299 minus the model call: `output` is the (B,7,7,10+C) prediction.  Appends rows
+    [img, conf, x1,y1,x2,y2] to detects[c] and [img, 1, x1,y1,x2,y2] to targets[label-1]."""
+    detects = detects if detects is not None else {i: [] for i in range(num_classes)}
+    targets = targets if targets is not None else {i: [] for i in range(num_classes)}
+    box, label, conf, score, count, keep, kcnt, tbox, tlabel = decode_nms_batched(
+        output, target, 0.2, prob_threshold, nms_threshold)
+    box, label, conf = box.cpu(), label.cpu(), conf.cpu()
+    keep, kcnt, tbox, tlabel = keep.cpu(), kcnt.cpu(), tbox.cpu(), tlabel.cpu()
+    for i in range(box.shape[0]):
+        targets[int(tlabel[i]) - 1].append([i, 1] + tbox[i].tolist())
+        k = int(kcnt[i])
+        if k == 0:
+            continue
+        ids = keep[i, :k]
+        b, l, c = box[i][ids], label[i][ids], conf[i][ids]
+        for cls in range(num_classes):
+            sel = l == cls
+            if sel.sum() == 0:
+                continue
+            pred = torch.cat([c[sel].view(-1, 1), b[sel].view(-1, 4)], dim=1)
+            for row in pred:
+                detects[cls].append([i] + row.tolist())
+    return detects, targets
+
+
+def ap(detects, targets, iou_threds=0.01):
+    """VOC-style AP (yolo.py:306-367).  All detection-vs-GT IoUs of a class are computed in one
+    elementwise-IoU launch; the greedy TP/FP matching and the PR envelope stay on the host as in
+    the reference.  Like the reference, an empty class appends 0.0 and then still appends its AP."""
+    aps = []
+    for c in targets.keys():
+        if len(targets[c]) == 0:
+            aps.append(0.0)
+        n_grt = len(targets[c])
+        grts = {i[0]: i[2:] for i in targets[c]}
+        hit = {k: 0 for k in grts}
+        det = sorted(list(detects[c]), key=lambda x: x[1], reverse=True)
+        TP, FP = np.zeros(len(det)), np.zeros(len(det))
+        has = [d[0] in grts for d in det]
+        ious = np.full(len(det), -np.inf)
+        if any(has):
+            db = torch.tensor([d[2:] for d, h in zip(det, has) if h], dtype=torch.float32)
+            gb = torch.tensor([grts[d[0]] for d, h in zip(det, has) if h], dtype=torch.float32)
+            ious[np.array(has)] = get_iou(db, gb).numpy()
+        for d in range(len(det)):
+            if ious[d] >= iou_threds:
+                if hit[det[d][0]] == 0:
+                    TP[d] = 1
+                    hit[det[d][0]] = 1
+                else:
+                    FP[d] = 1
+            else:
+                FP[d] = 1
+        tp_sum, fp_sum = np.cumsum(TP), np.cumsum(FP)
+        with np.errstate(all="ignore"):
+            recall = tp_sum / n_grt
+            prec = np.divide(tp_sum, tp_sum + fp_sum)
+        recall = np.concatenate(([0.0], recall, [1.0]))
+        prec = np.concatenate(([0.0], prec, [0.0]))
+        for i in range(prec.size - 1, 0, -1):
+            prec[i - 1] = max(prec[i - 1], prec[i])
+        a = 0.0
+        for i in range(prec.size - 1):
+            a += (recall[i + 1] - recall[i]) * prec[i + 1]
+        aps.append(a)
+    return aps
