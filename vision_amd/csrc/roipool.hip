@@ -63,14 +63,16 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc(const float *__restrict__ 
 // ---------------------------------------------------------------- forward
 template <int MODE>
 __global__ __launch_bounds__(64) void k_roipool_fwd(const float *__restrict__ nhwc, int C, int H, int W,
-                                                    const int32_t *__restrict__ win, float *__restrict__ out,
+                                                    const int32_t *__restrict__ win, int cblocks, float *__restrict__ out,
                                                     int32_t *__restrict__ argmax, int vec_ok)
 {
     __shared__ __attribute__((aligned(16))) float sval[64 * RBINS];
     __shared__ __attribute__((aligned(16))) unsigned short sidx[64 * RBINS];
     const int lane = threadIdx.x;
-    const int c0 = blockIdx.x * 64;
-    const int64_t roi = blockIdx.y;
+    // 1-D grid, channel block fastest: blocks that share an XCD (blockIdx % 8) share a channel slice
+    const int cbk = blockIdx.x % cblocks;
+    const int64_t roi = blockIdx.x / cblocks;
+    const int c0 = cbk * 64;
     const int32_t *w = win + 5 * roi;
     const int x1 = w[0], y1 = w[1], x2 = w[2], y2 = w[3], b = w[4];
     const int Lh = y2 - y1, Lw = x2 - x1;
@@ -247,16 +249,12 @@ extern "C" int dg_roipool_fwd_f32(const float *img_nhwc, int64_t B, int64_t C, i
     int vec_ok = (C % 4 == 0) && ((((uintptr_t)out) & 15) == 0) && (!argmax || (((uintptr_t)argmax) & 15) == 0);
     hipStream_t st = (hipStream_t)s;
     const int64_t cblocks = dg_cdiv(C, 64);
-    for (int64_t r0 = 0; r0 < n; r0 += 65535) {          // gridDim.y limit
-        int64_t nr = (n - r0) < 65535 ? (n - r0) : 65535;
-        dim3 grid((unsigned)cblocks, (unsigned)nr);
-        float *o = out + r0 * C * RBINS;
-        int32_t *a = argmax ? argmax + r0 * C * RBINS : nullptr;
-        if (mode == DG_POOL_MAX)
-            hipLaunchKernelGGL((k_roipool_fwd<DG_POOL_MAX>), grid, dim3(64), 0, st, img_nhwc, (int)C, (int)H, (int)W, win + 5 * r0, o, a, vec_ok);
-        else
-            hipLaunchKernelGGL((k_roipool_fwd<DG_POOL_AVG>), grid, dim3(64), 0, st, img_nhwc, (int)C, (int)H, (int)W, win + 5 * r0, o, a, vec_ok);
-    }
+    DG_REQUIRE(n * cblocks < (1ll << 31), "roipool_fwd: n * ceil(C/64) must be < 2^31");
+    dim3 grid((unsigned)(n * cblocks));
+    if (mode == DG_POOL_MAX)
+        hipLaunchKernelGGL((k_roipool_fwd<DG_POOL_MAX>), grid, dim3(64), 0, st, img_nhwc, (int)C, (int)H, (int)W, win, (int)cblocks, out, argmax, vec_ok);
+    else
+        hipLaunchKernelGGL((k_roipool_fwd<DG_POOL_AVG>), grid, dim3(64), 0, st, img_nhwc, (int)C, (int)H, (int)W, win, (int)cblocks, out, argmax, vec_ok);
     DG_CHECK_LAUNCH("k_roipool_fwd");
     return DG_OK;
 }
