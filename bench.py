@@ -115,10 +115,10 @@ class FrcnnBatch:
         self.win, self.status = self.ops.roi_windows(self.rois, self.idx, self.B, self.shape[2], self.shape[3], self.d.dev)
 
     def stage(self):
-        self.nhwc = self.ops.to_nhwc(self.img)
+        self.nhwc, self.nanf = self.ops.to_nhwc(self.img)
 
     def fwd(self):
-        self.ops.roipool_forward(self.img, self.win, "max", out=self.out, argmax=self.arg, nhwc=self.nhwc)
+        self.ops.roipool_forward(self.img, self.win, "max", out=self.out, argmax=self.arg, nhwc=self.nhwc, nan_flag=self.nanf)
 
     def bwd(self):
         self.ops.roipool_backward(self.gout, self.arg, self.win, self.shape, "max", grad_in=self.gin)

@@ -99,12 +99,17 @@ int dg_yolo2_decode_anchor_f32(const float *pred, int64_t G, int64_t A, int64_t 
  * an image index is out of range. */
 int dg_roi_windows(const double *rois, const int64_t *roi_idx, int64_t n, int64_t B, int64_t H, int64_t W,
                    int32_t *win, int32_t *status, dg_stream_t s);
-/* (B,C,H,W) -> (B,H,W,C) staging copy used by the forward kernel (lanes = channels). */
-int dg_nchw_to_nhwc_f32(const float *src, int64_t B, int64_t C, int64_t H, int64_t W, float *dst, dg_stream_t s);
+/* (B,C,H,W) -> (B,H,W,C) staging copy used by the forward kernel (lanes = channels).  nan_flag (device
+ * int32, zeroed by the caller, may be NULL) is OR-ed with 1 if the map holds a NaN. */
+int dg_nchw_to_nhwc_f32(const float *src, int64_t B, int64_t C, int64_t H, int64_t W, float *dst, int32_t *nan_flag,
+                        dg_stream_t s);
 /* forward: img_nhwc (B,H,W,C), win from dg_roi_windows; out (n,C,P,P) fp32; argmax (n,C,P,P) int32
- * = flat index y*W+x in the feature-map plane (DG_POOL_MAX only, may be NULL).  P must be 7. */
+ * = flat index y*W+x in the feature-map plane (DG_POOL_MAX only, may be NULL).  P must be 7.
+ * nan_flag: the word dg_nchw_to_nhwc_f32 wrote (0 = no NaN in the map: the kernel skips ATen's "NaN always
+ * wins" test), or NULL = unknown (NaN-exact path). */
 int dg_roipool_fwd_f32(const float *img_nhwc, int64_t B, int64_t C, int64_t H, int64_t W,
-                       const int32_t *win, int64_t n, int64_t P, int mode, float *out, int32_t *argmax, dg_stream_t s);
+                       const int32_t *win, int64_t n, int64_t P, int mode, const int32_t *nan_flag,
+                       float *out, int32_t *argmax, dg_stream_t s);
 /* R2 backward (autograd in the reference).  grad_out (n,C,P,P), argmax from the forward (max mode);
  * grad_in (B,C,H,W) is overwritten (not accumulated).  Workspace holds the per-image RoI lists. */
 size_t dg_roipool_bwd_workspace_bytes(int64_t B, int64_t n);

@@ -1,0 +1,45 @@
+"""Profiling driver: runs one hot-path phase a few times (used under rocprofv3).
+usage: python3 tools/prof_roi.py {fwd|bwd|kmeans|nms64k|pairwise} [images]"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from vision_amd import ops, workloads as wl  # noqa: E402
+
+what = sys.argv[1] if len(sys.argv) > 1 else "fwd"
+images = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+dev = torch.device("cuda", 0)
+if what in ("fwd", "bwd"):
+    img = torch.randn((images, 512, 38, 50), device=dev)
+    rois = torch.from_numpy(np.concatenate([wl.frcnn_rois(i) for i in range(images)])).to(dev)
+    idx = torch.arange(images, device=dev).repeat_interleave(2000)
+    win, st = ops.roi_windows(rois, idx, images, 38, 50, dev)
+    nhwc, nanf = ops.to_nhwc(img)
+    out, arg = ops.roipool_forward(img, win, "max", nhwc=nhwc, nan_flag=nanf)
+    for _ in range(3):
+        if what == "fwd":
+            ops.roipool_forward(img, win, "max", out=out, argmax=arg, nhwc=nhwc, nan_flag=nanf)
+        else:
+            ops.roipool_backward(out, arg, win, img.shape, "max")
+elif what == "kmeans":
+    wh = torch.from_numpy(wl.anchor_wh(0, 10_000_000)).to(dev)
+    cent = wh[:5].clone()
+    labels = torch.zeros(wh.shape[0], dtype=torch.uint8, device=dev)
+    acc = torch.zeros(17, dtype=torch.int64, device=dev)
+    for _ in range(4):
+        ops.kmeans_step(wh, cent, labels, acc)
+elif what == "nms64k":
+    b, s = wl.stress_boxes(0, 65536, dense=False)
+    for _ in range(2):
+        ops.nms_batched(torch.from_numpy(b).to(dev).reshape(1, -1, 4), torch.from_numpy(s).to(dev).reshape(1, -1), None, 0.5, True)
+elif what == "pairwise":
+    b, s = wl.stress_boxes(0, 32768, dense=False)
+    bt = torch.from_numpy(b).to(dev)
+    for _ in range(3):
+        ops.iou_pairwise(bt, bt)
+torch.cuda.synchronize()
+print("done", what)

@@ -41,7 +41,8 @@ __global__ __launch_bounds__(256) void k_roi_windows(const double *__restrict__ 
 }
 
 // ---------------------------------------------------------------- NCHW -> NHWC staging copy
-__global__ __launch_bounds__(256) void k_nchw_to_nhwc(const float *__restrict__ src, int C, int HW, float *__restrict__ dst)
+__global__ __launch_bounds__(256) void k_nchw_to_nhwc(const float *__restrict__ src, int C, int HW, float *__restrict__ dst,
+                                                      int32_t *__restrict__ nan_flag)
 {
     __shared__ float tile[64][65];
     const int b = blockIdx.z;
@@ -49,10 +50,14 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc(const float *__restrict__ 
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     src += (int64_t)b * C * HW;
     dst += (int64_t)b * C * HW;
+    bool nan = false;
     for (int k = ty; k < 64; k += 4) {
         int c = c0 + k, p = p0 + tx;
-        tile[k][tx] = (c < C && p < HW) ? src[(int64_t)c * HW + p] : 0.f;
+        float v = (c < C && p < HW) ? src[(int64_t)c * HW + p] : 0.f;
+        nan |= (v != v);
+        tile[k][tx] = v;
     }
+    if (nan_flag && __ballot(nan) != 0 && tx == 0) atomicOr(nan_flag, 1);   // lets the pooling kernel skip NaN handling
     __syncthreads();
     for (int k = ty; k < 64; k += 4) {
         int p = p0 + k, c = c0 + tx;
@@ -61,85 +66,235 @@ __global__ __launch_bounds__(256) void k_nchw_to_nhwc(const float *__restrict__ 
 }
 
 // ---------------------------------------------------------------- forward
-template <int MODE>
-__global__ __launch_bounds__(64) void k_roipool_fwd(const float *__restrict__ nhwc, int C, int H, int W,
-                                                    const int32_t *__restrict__ win, int cblocks, float *__restrict__ out,
-                                                    int32_t *__restrict__ argmax, int vec_ok)
+// Max update in ATen's order (AdaptiveMaxPool2d CPU kernel): first maximum wins, a NaN always wins.
+template <bool NANSAFE>
+__device__ __forceinline__ void max_upd(float &best, int &bi, float v, int idx)
 {
-    __shared__ __attribute__((aligned(16))) float sval[64 * RBINS];
-    __shared__ __attribute__((aligned(16))) unsigned short sidx[64 * RBINS];
-    const int lane = threadIdx.x;
-    // 1-D grid, channel block fastest: blocks that share an XCD (blockIdx % 8) share a channel slice
-    const int cbk = blockIdx.x % cblocks;
-    const int64_t roi = blockIdx.x / cblocks;
-    const int c0 = cbk * 64;
-    const int32_t *w = win + 5 * roi;
-    const int x1 = w[0], y1 = w[1], x2 = w[2], y2 = w[3], b = w[4];
-    const int Lh = y2 - y1, Lw = x2 - x1;
-    const int cvalid = (C - c0) < 64 ? (C - c0) : 64;
-    const int c = c0 + (lane < cvalid ? lane : cvalid - 1);
-    const float *base = nhwc + (int64_t)b * H * W * C + c;
+    if (NANSAFE) { if ((v > best) || (v != v)) { best = v; bi = idx; } }
+    else         { if (v > best) { best = v; bi = idx; } }
+}
 
-#pragma unroll 1
+#define RING_PX 64                       // crop pixels (x 64 channels x 4 B = 16 KiB) resident in LDS per wave
+#define FWD_LDS_FLOATS (64 * RBINS + 64 * RBINS / 2)   // [64][49] f32 values + [64][49] u16 indices = 18,816 B
+
+// Staged task: the crop's rows stream into an LDS ring by LDS-DMA (global_load_lds, 16 B per lane = 4 pixels x
+// 64 channels per wave instruction); every crop row is fetched once and the next strip's rows are in flight
+// while the current strip is pooled out of LDS.  For each row the 7 column bins are scanned together, XW
+// pixels each (positions past a bin's end are clamped re-reads of its last pixel: idempotent), from
+// per-(bin,j) LDS addresses computed once per task.  All 49 results stay in registers (the 7 strips are
+// unrolled), so the [channel][bin] transpose buffer can alias the ring: 18.8 KB of LDS per wave, 8 waves/CU.
+template <int XW, bool NANSAFE>
+__device__ __forceinline__ void roi_task_staged(char *smem, const float *__restrict__ nhwc, int C, int H, int W, int lane,
+                                                int x1, int y1, int x2, int y2, int b, int c0, int R,
+                                                float (&oval)[RBINS], int (&oidx)[RBINS])
+{
+    const int Lh = y2 - y1, Lw = x2 - x1, Lwp = (Lw + 3) & ~3;
+    const int rowbytes = Lwp * 256;
+    int ws[RP], we[RP];
+    int addr[RP][XW];                                   // byte address of (bin, j) inside a ring row, + lane*4
+#pragma unroll
+    for (int i = 0; i < RP; ++i) {
+        ws[i] = (i * Lw) / RP;                          // relative to x1
+        we[i] = ((i + 1) * Lw + RP - 1) / RP;
+#pragma unroll
+        for (int j = 0; j < XW; ++j) addr[i][j] = min(ws[i] + j, we[i] - 1) * 256 + lane * 4;
+    }
+    // LDS-DMA source: this lane moves channel quad (lane & 15) of pixel (lane >> 4) of each group of 4 pixels
+    const char *gq = (const char *)(nhwc + ((int64_t)b * H * W) * C + c0 + (lane & 15) * 4);
+    const int pxl = lane >> 4;
+    const int64_t pixbytes = (int64_t)C * 4;
+    int loaded = y1, lslot = 0;
+    auto issue_rows = [&](int ylimit) {
+        for (; loaded < ylimit; ++loaded) {
+            const char *rowg = gq + ((int64_t)loaded * W + x1) * pixbytes;
+            char *rowl = smem + lslot * rowbytes;
+            for (int q = 0; q < Lwp; q += 4) {
+                const int px = min(q + pxl, Lw - 1);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rowg + px * pixbytes),
+                                                 (__attribute__((address_space(3))) void *)(rowl + q * 256), 16, 0, 0);
+            }
+            lslot = (lslot + 1 == R) ? 0 : lslot + 1;
+        }
+    };
+    issue_rows(min(y2, y1 + R));
+#pragma unroll
     for (int ph = 0; ph < RP; ++ph) {
         const int hs = y1 + (ph * Lh) / RP, he = y1 + ((ph + 1) * Lh + RP - 1) / RP;
-#pragma unroll 1
-        for (int pw = 0; pw < RP; ++pw) {
-            const int ws = x1 + (pw * Lw) / RP, we = x1 + ((pw + 1) * Lw + RP - 1) / RP;
-            if (MODE == DG_POOL_MAX) {
-                float best = -INFINITY;
-                int bi = hs * W + ws;
-                for (int y = hs; y < he; ++y) {
-                    const float *row = base + (int64_t)y * W * C;
-                    for (int x = ws; x < we; x += 4) {
-                        // 4 independent loads in flight; positions past the bin are clamped re-reads
-                        // and masked out of the update (ATen: first max wins, NaN always wins)
-                        const int xa = x, xb = min(x + 1, we - 1), xc = min(x + 2, we - 1), xd = min(x + 3, we - 1);
-                        const float va = row[(int64_t)xa * C], vb = row[(int64_t)xb * C];
-                        const float vc = row[(int64_t)xc * C], vd = row[(int64_t)xd * C];
-                        if ((va > best) || (va != va)) { best = va; bi = y * W + xa; }
-                        if ((x + 1 < we) && ((vb > best) || (vb != vb))) { best = vb; bi = y * W + xb; }
-                        if ((x + 2 < we) && ((vc > best) || (vc != vc))) { best = vc; bi = y * W + xc; }
-                        if ((x + 3 < we) && ((vd > best) || (vd != vd))) { best = vd; bi = y * W + xd; }
-                    }
-                }
-                sval[lane * RBINS + ph * RP + pw] = best;
-                sidx[lane * RBINS + ph * RP + pw] = (unsigned short)bi;
-            } else {
-                float sum = 0.f;
-                for (int y = hs; y < he; ++y) {
-                    const float *row = base + (int64_t)y * W * C;
-                    for (int x = ws; x < we; ++x) sum += row[(int64_t)x * C];
-                }
-                sval[lane * RBINS + ph * RP + pw] = sum / (float)(he - hs) / (float)(we - ws);
+        issue_rows(he);                                    // normally already issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // rows < he have landed
+        issue_rows(min(y2, hs + R));                       // prefetch; only overwrites rows < hs
+        float best[RP];
+        int code[RP];                                      // (row in strip) * 8 + j of the current maximum
+#pragma unroll
+        for (int i = 0; i < RP; ++i) { best[i] = -INFINITY; code[i] = 0; }
+        int slot = (hs - y1) % R;
+        int rowoff = slot * rowbytes;
+        for (int r = 0; r < he - hs; ++r) {
+#pragma unroll
+            for (int j = 0; j < XW; ++j) {
+                const int cj = r * 8 + j;
+#pragma unroll
+                for (int i = 0; i < RP; ++i)
+                    max_upd<NANSAFE>(best[i], code[i], *(const float *)(smem + (addr[i][j] + rowoff)), cj);
             }
+            rowoff += rowbytes;
+            if (++slot == R) { slot = 0; rowoff = 0; }
         }
-    }
-    __syncthreads();
-    // contiguous run of cvalid*49 outputs for this (roi, channel block)
-    const int64_t obase = (roi * C + c0) * RBINS;
-    const int total = cvalid * RBINS;
-    if (vec_ok) {
-        for (int e = lane * 4; e < total; e += 256) {
-            *reinterpret_cast<float4 *>(out + obase + e) = *reinterpret_cast<const float4 *>(sval + e);
-            if (MODE == DG_POOL_MAX && argmax) {
-                const ushort4 u = *reinterpret_cast<const ushort4 *>(sidx + e);
-                *reinterpret_cast<int4 *>(argmax + obase + e) = make_int4(u.x, u.y, u.z, u.w);
-            }
-        }
-    } else {
-        for (int e = lane; e < total; e += 64) {
-            out[obase + e] = sval[e];
-            if (MODE == DG_POOL_MAX && argmax) argmax[obase + e] = sidx[e];
+#pragma unroll
+        for (int i = 0; i < RP; ++i) {
+            oval[ph * RP + i] = best[i];
+            oidx[ph * RP + i] = (hs + (code[i] >> 3)) * W + x1 + min(ws[i] + (code[i] & 7), we[i] - 1);
         }
     }
 }
 
+template <int MODE>
+__global__ __launch_bounds__(64) void k_roipool_fwd(const float *__restrict__ nhwc, int C, int H, int W,
+                                                    const int32_t *__restrict__ win, int cblocks, int64_t ntasks,
+                                                    const int32_t *__restrict__ nan_flag,
+                                                    float *__restrict__ out, int32_t *__restrict__ argmax, int vec_ok)
+{
+    __shared__ __attribute__((aligned(16))) float smemf[FWD_LDS_FLOATS];
+    float *sval = smemf;
+    unsigned short *sidx = reinterpret_cast<unsigned short *>(smemf + 64 * RBINS);
+    const int lane = threadIdx.x;
+    const bool may_nan = nan_flag ? (__builtin_amdgcn_readfirstlane(nan_flag[0]) != 0) : true;
+    // Persistent single-wave workgroups.  Task = (RoI, 64-channel block), channel block fastest; the grid is a
+    // multiple of 8, so a workgroup (and the XCD it sits on, blockIdx % 8) keeps one channel slice of the map.
+#pragma unroll 1
+    for (int64_t task = blockIdx.x; task < ntasks; task += gridDim.x) {
+        const int cbk = (int)(task % cblocks);
+        const int64_t roi = task / cblocks;
+        const int c0 = cbk * 64;
+        const int32_t *w = win + 5 * roi;
+        const int x1 = __builtin_amdgcn_readfirstlane(w[0]), y1 = __builtin_amdgcn_readfirstlane(w[1]);
+        const int x2 = __builtin_amdgcn_readfirstlane(w[2]), y2 = __builtin_amdgcn_readfirstlane(w[3]);
+        const int b = __builtin_amdgcn_readfirstlane(w[4]);
+        const int Lh = y2 - y1, Lw = x2 - x1;
+        const int cvalid = (C - c0) < 64 ? (C - c0) : 64;
+
+        bool staged = false;
+        if (MODE == DG_POOL_MAX) {
+            const int Lwp = (Lw + 3) & ~3;
+            const int R = RING_PX / Lwp;
+            int maxw = 0, maxrows = 0;                                     // widest / tallest adaptive bin
+#pragma unroll
+            for (int i = 0; i < RP; ++i) {
+                maxw = max(maxw, ((i + 1) * Lw + RP - 1) / RP - (i * Lw) / RP);
+                maxrows = max(maxrows, ((i + 1) * Lh + RP - 1) / RP - (i * Lh) / RP);
+            }
+            staged = (R >= maxrows) && (maxw <= 4) && (maxrows <= 8) && (cvalid == 64) && ((C & 3) == 0) &&
+                     ((((uintptr_t)nhwc) & 15) == 0);
+            if (staged) {
+                float oval[RBINS];
+                int oidx[RBINS];
+                char *smem = reinterpret_cast<char *>(smemf);
+#define STAGED(XWV)                                                                                                         \
+    if (may_nan) roi_task_staged<XWV, true>(smem, nhwc, C, H, W, lane, x1, y1, x2, y2, b, c0, R, oval, oidx);               \
+    else roi_task_staged<XWV, false>(smem, nhwc, C, H, W, lane, x1, y1, x2, y2, b, c0, R, oval, oidx)
+                switch (maxw) {
+                case 1: STAGED(1); break;
+                case 2: STAGED(2); break;
+                case 3: STAGED(3); break;
+                default: STAGED(4); break;
+                }
+#undef STAGED
+                // all ring reads are done (results are in registers): the transpose buffer may overwrite the ring
+#pragma unroll
+                for (int i = 0; i < RBINS; ++i) {
+                    sval[lane * RBINS + i] = oval[i];
+                    sidx[lane * RBINS + i] = (unsigned short)oidx[i];
+                }
+            }
+        }
+        if (!staged) {
+            // ---- direct path (any crop size, partial channel blocks, avg mode): reads the map from L2/HBM per bin
+            const int c = c0 + (lane < cvalid ? lane : cvalid - 1);
+            const float *base = nhwc + (int64_t)b * H * W * C + c;
+#pragma unroll 1
+            for (int ph = 0; ph < RP; ++ph) {
+                const int hs = y1 + (ph * Lh) / RP, he = y1 + ((ph + 1) * Lh + RP - 1) / RP;
+#pragma unroll 1
+                for (int pw = 0; pw < RP; ++pw) {
+                    const int ws = x1 + (pw * Lw) / RP, we = x1 + ((pw + 1) * Lw + RP - 1) / RP;
+                    if (MODE == DG_POOL_MAX) {
+                        float best = -INFINITY;
+                        int bi = hs * W + ws;
+                        for (int y = hs; y < he; ++y) {
+                            const float *row = base + (int64_t)y * W * C;
+                            for (int x = ws; x < we; x += 4) {
+                                // 4 independent loads in flight; past the bin's end: clamped re-reads (idempotent)
+                                const int xb = min(x + 1, we - 1), xc = min(x + 2, we - 1), xd = min(x + 3, we - 1);
+                                const float va = row[(int64_t)x * C], vb = row[(int64_t)xb * C];
+                                const float vc = row[(int64_t)xc * C], vd = row[(int64_t)xd * C];
+                                max_upd<true>(best, bi, va, y * W + x);
+                                max_upd<true>(best, bi, vb, y * W + xb);
+                                max_upd<true>(best, bi, vc, y * W + xc);
+                                max_upd<true>(best, bi, vd, y * W + xd);
+                            }
+                        }
+                        sval[lane * RBINS + ph * RP + pw] = best;
+                        sidx[lane * RBINS + ph * RP + pw] = (unsigned short)bi;
+                    } else {
+                        float sum = 0.f;
+                        for (int y = hs; y < he; ++y) {
+                            const float *row = base + (int64_t)y * W * C;
+                            for (int x = ws; x < we; ++x) sum += row[(int64_t)x * C];
+                        }
+                        sval[lane * RBINS + ph * RP + pw] = sum / (float)(he - hs) / (float)(we - ws);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // contiguous run of cvalid*49 outputs for this (roi, channel block)
+        const int64_t obase = (roi * C + c0) * RBINS;
+        const int total = cvalid * RBINS;
+        if (vec_ok) {
+            for (int e = lane * 4; e < total; e += 256) {
+                *reinterpret_cast<float4 *>(out + obase + e) = *reinterpret_cast<const float4 *>(sval + e);
+                if (MODE == DG_POOL_MAX && argmax) {
+                    const ushort4 u = *reinterpret_cast<const ushort4 *>(sidx + e);
+                    *reinterpret_cast<int4 *>(argmax + obase + e) = make_int4(u.x, u.y, u.z, u.w);
+                }
+            }
+        } else {
+            for (int e = lane; e < total; e += 64) {
+                out[obase + e] = sval[e];
+                if (MODE == DG_POOL_MAX && argmax) argmax[obase + e] = sidx[e];
+            }
+        }
+        __syncthreads();      // the buffer is reused by the next task's ring
+    }
+}
+
 // ---------------------------------------------------------------- backward: per-image RoI lists
+// RoIs usually arrive grouped by image, so a wave sees one or two image ids: one atomic per distinct id
+// per wave (leader lane adds the group's size) instead of 64 colliding atomics.
+__device__ __forceinline__ int wave_group_add(int32_t *counter_base, int key, bool valid, int *rank_in_group)
+{
+    const int lane = threadIdx.x & 63;
+    int start = 0;
+    *rank_in_group = 0;
+    u64 todo = __ballot(valid);
+    while (todo) {
+        const int leader = __builtin_ctzll(todo);
+        const int k = __shfl(key, leader, 64);
+        const u64 grp = __ballot(valid && key == k);
+        int base = 0;
+        if (lane == leader) base = atomicAdd(&counter_base[k], __builtin_popcountll(grp));
+        base = __shfl(base, leader, 64);
+        if (valid && key == k) { start = base; *rank_in_group = __builtin_popcountll(grp & ((1ull << lane) - 1ull)); }
+        todo &= ~grp;
+    }
+    return start;
+}
 __global__ __launch_bounds__(256) void k_roi_count(const int32_t *__restrict__ win, int64_t n, int32_t *__restrict__ cnt)
 {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) atomicAdd(&cnt[win[5 * i + 4]], 1);
+    const bool valid = i < n;
+    int r;
+    wave_group_add(cnt, valid ? win[5 * i + 4] : 0, valid, &r);
 }
 // exclusive scan of cnt[0..B) into off[0..B]; cursor[] = off[] ; single workgroup
 __global__ __launch_bounds__(1024) void k_roi_scan(const int32_t *__restrict__ cnt, int B, int32_t *__restrict__ off,
@@ -169,11 +324,16 @@ __global__ __launch_bounds__(256) void k_roi_fill(const int32_t *__restrict__ wi
                                                   int32_t *__restrict__ list)
 {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) list[atomicAdd(&cursor[win[5 * i + 4]], 1)] = (int32_t)i;
+    const bool valid = i < n;
+    int r;
+    const int start = wave_group_add(cursor, valid ? win[5 * i + 4] : 0, valid, &r);
+    if (valid) list[start + r] = (int32_t)i;
 }
 
 // grid: x = channel block (CB channels), y = image.  Dynamic LDS: CB*H*W floats.
-template <int MODE>
+// VEC: CB*49 % 4 == 0 and 16-byte aligned tensors -> each thread moves 4 consecutive elements of one RoI
+// (16-byte loads of grad_out and argmax), two such groups in flight per thread.
+template <int MODE, bool VEC>
 __global__ __launch_bounds__(256) void k_roipool_bwd(const float *__restrict__ grad_out, const int32_t *__restrict__ argmax,
                                                      const int32_t *__restrict__ win, const int32_t *__restrict__ off,
                                                      const int32_t *__restrict__ list, int C, int H, int W, int CB,
@@ -188,24 +348,61 @@ __global__ __launch_bounds__(256) void k_roipool_bwd(const float *__restrict__ g
     __syncthreads();
     const int r0 = off[b], r1 = off[b + 1];
     const int per = cb * RBINS;                      // contiguous elements per RoI for this channel slice
-    const int64_t work = (int64_t)(r1 - r0) * per;
-    for (int64_t t = tid; t < work; t += 256) {
-        const int rr = (int)(t / per), e = (int)(t - (int64_t)rr * per);
-        const int roi = list[r0 + rr];
-        const int64_t o = ((int64_t)roi * C + c0) * RBINS + e;
-        const float g = grad_out[o];
-        const int ch = e / RBINS;
-        if (MODE == DG_POOL_MAX) {
-            atomicAdd(&plane[ch * HW + argmax[o]], g);
-        } else {
-            const int bin = e - ch * RBINS, ph = bin / RP, pw = bin - ph * RP;
-            const int32_t *w = win + 5 * (int64_t)roi;
-            const int x1 = w[0], y1 = w[1], Lw = w[2] - x1, Lh = w[3] - y1;
-            const int hs = y1 + (ph * Lh) / RP, he = y1 + ((ph + 1) * Lh + RP - 1) / RP;
-            const int ws = x1 + (pw * Lw) / RP, we = x1 + ((pw + 1) * Lw + RP - 1) / RP;
-            const float gd = g / (float)(he - hs) / (float)(we - ws);
-            for (int y = hs; y < he; ++y)
-                for (int x = ws; x < we; ++x) atomicAdd(&plane[ch * HW + y * W + x], gd);
+    if (MODE == DG_POOL_MAX && VEC) {
+        const int per4 = per >> 2;                   // float4 groups per RoI
+        const int64_t work = (int64_t)(r1 - r0) * per4;
+        int64_t t = tid;
+        for (; t + 256 < work; t += 512) {           // two independent 16-byte pairs in flight
+            const int64_t t2 = t + 256;
+            const int ra = (int)(t / per4), qa = (int)(t - (int64_t)ra * per4);
+            const int rb = (int)(t2 / per4), qb = (int)(t2 - (int64_t)rb * per4);
+            const int64_t oa = ((int64_t)list[r0 + ra] * C + c0) * RBINS + 4 * qa;
+            const int64_t ob = ((int64_t)list[r0 + rb] * C + c0) * RBINS + 4 * qb;
+            const float4 ga = *reinterpret_cast<const float4 *>(grad_out + oa);
+            const int4 ia = *reinterpret_cast<const int4 *>(argmax + oa);
+            const float4 gb = *reinterpret_cast<const float4 *>(grad_out + ob);
+            const int4 ib = *reinterpret_cast<const int4 *>(argmax + ob);
+            const int ea = 4 * qa, eb = 4 * qb;
+            atomicAdd(&plane[((ea + 0) / RBINS) * HW + ia.x], ga.x);
+            atomicAdd(&plane[((ea + 1) / RBINS) * HW + ia.y], ga.y);
+            atomicAdd(&plane[((ea + 2) / RBINS) * HW + ia.z], ga.z);
+            atomicAdd(&plane[((ea + 3) / RBINS) * HW + ia.w], ga.w);
+            atomicAdd(&plane[((eb + 0) / RBINS) * HW + ib.x], gb.x);
+            atomicAdd(&plane[((eb + 1) / RBINS) * HW + ib.y], gb.y);
+            atomicAdd(&plane[((eb + 2) / RBINS) * HW + ib.z], gb.z);
+            atomicAdd(&plane[((eb + 3) / RBINS) * HW + ib.w], gb.w);
+        }
+        for (; t < work; t += 256) {
+            const int ra = (int)(t / per4), qa = (int)(t - (int64_t)ra * per4);
+            const int64_t oa = ((int64_t)list[r0 + ra] * C + c0) * RBINS + 4 * qa;
+            const float4 ga = *reinterpret_cast<const float4 *>(grad_out + oa);
+            const int4 ia = *reinterpret_cast<const int4 *>(argmax + oa);
+            const int ea = 4 * qa;
+            atomicAdd(&plane[((ea + 0) / RBINS) * HW + ia.x], ga.x);
+            atomicAdd(&plane[((ea + 1) / RBINS) * HW + ia.y], ga.y);
+            atomicAdd(&plane[((ea + 2) / RBINS) * HW + ia.z], ga.z);
+            atomicAdd(&plane[((ea + 3) / RBINS) * HW + ia.w], ga.w);
+        }
+    } else {
+        const int64_t work = (int64_t)(r1 - r0) * per;
+        for (int64_t t = tid; t < work; t += 256) {
+            const int rr = (int)(t / per), e = (int)(t - (int64_t)rr * per);
+            const int roi = list[r0 + rr];
+            const int64_t o = ((int64_t)roi * C + c0) * RBINS + e;
+            const float g = grad_out[o];
+            const int ch = e / RBINS;
+            if (MODE == DG_POOL_MAX) {
+                atomicAdd(&plane[ch * HW + argmax[o]], g);
+            } else {
+                const int bin = e - ch * RBINS, ph = bin / RP, pw = bin - ph * RP;
+                const int32_t *w = win + 5 * (int64_t)roi;
+                const int x1 = w[0], y1 = w[1], Lw = w[2] - x1, Lh = w[3] - y1;
+                const int hs = y1 + (ph * Lh) / RP, he = y1 + ((ph + 1) * Lh + RP - 1) / RP;
+                const int ws = x1 + (pw * Lw) / RP, we = x1 + ((pw + 1) * Lw + RP - 1) / RP;
+                const float gd = g / (float)(he - hs) / (float)(we - ws);
+                for (int y = hs; y < he; ++y)
+                    for (int x = ws; x < we; ++x) atomicAdd(&plane[ch * HW + y * W + x], gd);
+            }
         }
     }
     __syncthreads();
@@ -226,19 +423,21 @@ extern "C" int dg_roi_windows(const double *rois, const int64_t *roi_idx, int64_
     return DG_OK;
 }
 
-extern "C" int dg_nchw_to_nhwc_f32(const float *src, int64_t B, int64_t C, int64_t H, int64_t W, float *dst, dg_stream_t s)
+extern "C" int dg_nchw_to_nhwc_f32(const float *src, int64_t B, int64_t C, int64_t H, int64_t W, float *dst, int32_t *nan_flag,
+                                   dg_stream_t s)
 {
     DG_REQUIRE(B > 0 && C > 0 && H > 0 && W > 0, "nchw_to_nhwc: bad shape");
     DG_REQUIRE(src && dst, "nchw_to_nhwc: null pointer");
     DG_REQUIRE(B <= 65535 && dg_cdiv(C, 64) <= 65535, "nchw_to_nhwc: shape too large");
     dim3 grid((unsigned)dg_cdiv(H * W, 64), (unsigned)dg_cdiv(C, 64), (unsigned)B);
-    hipLaunchKernelGGL(k_nchw_to_nhwc, grid, dim3(256), 0, (hipStream_t)s, src, (int)C, (int)(H * W), dst);
+    hipLaunchKernelGGL(k_nchw_to_nhwc, grid, dim3(256), 0, (hipStream_t)s, src, (int)C, (int)(H * W), dst, nan_flag);
     DG_CHECK_LAUNCH("k_nchw_to_nhwc");
     return DG_OK;
 }
 
 extern "C" int dg_roipool_fwd_f32(const float *img_nhwc, int64_t B, int64_t C, int64_t H, int64_t W,
-                                  const int32_t *win, int64_t n, int64_t P, int mode, float *out, int32_t *argmax, dg_stream_t s)
+                                  const int32_t *win, int64_t n, int64_t P, int mode, const int32_t *nan_flag,
+                                  float *out, int32_t *argmax, dg_stream_t s)
 {
     DG_REQUIRE(n >= 0 && B > 0 && C > 0 && H > 0 && W > 0, "roipool_fwd: bad shape");
     DG_REQUIRE(P == RP, "roipool_fwd: only output_size 7 is built (got %lld)", (long long)P);
@@ -249,12 +448,13 @@ extern "C" int dg_roipool_fwd_f32(const float *img_nhwc, int64_t B, int64_t C, i
     int vec_ok = (C % 4 == 0) && ((((uintptr_t)out) & 15) == 0) && (!argmax || (((uintptr_t)argmax) & 15) == 0);
     hipStream_t st = (hipStream_t)s;
     const int64_t cblocks = dg_cdiv(C, 64);
-    DG_REQUIRE(n * cblocks < (1ll << 31), "roipool_fwd: n * ceil(C/64) must be < 2^31");
-    dim3 grid((unsigned)(n * cblocks));
+    const int64_t ntasks = n * cblocks;
+    const int64_t maxgrid = 256 * 8;                   // 256 CUs x 8 resident single-wave workgroups (18.8 KB LDS each)
+    dim3 grid((unsigned)(ntasks < maxgrid ? ntasks : maxgrid));
     if (mode == DG_POOL_MAX)
-        hipLaunchKernelGGL((k_roipool_fwd<DG_POOL_MAX>), grid, dim3(64), 0, st, img_nhwc, (int)C, (int)H, (int)W, win, (int)cblocks, out, argmax, vec_ok);
+        hipLaunchKernelGGL((k_roipool_fwd<DG_POOL_MAX>), grid, dim3(64), 0, st, img_nhwc, (int)C, (int)H, (int)W, win, (int)cblocks, ntasks, nan_flag, out, argmax, vec_ok);
     else
-        hipLaunchKernelGGL((k_roipool_fwd<DG_POOL_AVG>), grid, dim3(64), 0, st, img_nhwc, (int)C, (int)H, (int)W, win, (int)cblocks, out, argmax, vec_ok);
+        hipLaunchKernelGGL((k_roipool_fwd<DG_POOL_AVG>), grid, dim3(64), 0, st, img_nhwc, (int)C, (int)H, (int)W, win, (int)cblocks, ntasks, nan_flag, out, argmax, vec_ok);
     DG_CHECK_LAUNCH("k_roipool_fwd");
     return DG_OK;
 }
@@ -302,13 +502,19 @@ extern "C" int dg_roipool_bwd_f32(const float *grad_out, const int32_t *argmax, 
     if (n > 0) hipLaunchKernelGGL(k_roi_fill, dim3((unsigned)dg_cdiv(n, 256)), dim3(256), 0, st, win, n, w.cursor, w.list);
     // channels per workgroup: as many as fit ~32 KiB of LDS, but keep >= ~1024 workgroups when possible
     int CB = 1;
+    while (CB < 4 && (int64_t)CB * 2 * HW * 4 <= 32 * 1024 && CB * 2 <= C) CB *= 2;      // 4 channels: 16-byte vector path
     while (CB < 16 && (int64_t)CB * 2 * HW * 4 <= 32 * 1024 && B * dg_cdiv(C, CB * 2) >= 1024) CB *= 2;
     dim3 grid((unsigned)dg_cdiv(C, CB), (unsigned)B);
     size_t lds = (size_t)CB * HW * 4;
-    if (mode == DG_POOL_MAX)
-        hipLaunchKernelGGL((k_roipool_bwd<DG_POOL_MAX>), grid, dim3(256), lds, st, grad_out, argmax, win, w.off, w.list, (int)C, (int)H, (int)W, CB, grad_in);
+    // vector path: every channel slice is whole groups of 4 elements and 16-byte aligned
+    const bool vec = mode == DG_POOL_MAX && CB % 4 == 0 && C % CB == 0 &&
+                     ((((uintptr_t)grad_out) | ((uintptr_t)argmax)) & 15) == 0;
+    if (mode == DG_POOL_MAX && vec)
+        hipLaunchKernelGGL((k_roipool_bwd<DG_POOL_MAX, true>), grid, dim3(256), lds, st, grad_out, argmax, win, w.off, w.list, (int)C, (int)H, (int)W, CB, grad_in);
+    else if (mode == DG_POOL_MAX)
+        hipLaunchKernelGGL((k_roipool_bwd<DG_POOL_MAX, false>), grid, dim3(256), lds, st, grad_out, argmax, win, w.off, w.list, (int)C, (int)H, (int)W, CB, grad_in);
     else
-        hipLaunchKernelGGL((k_roipool_bwd<DG_POOL_AVG>), grid, dim3(256), lds, st, grad_out, argmax, win, w.off, w.list, (int)C, (int)H, (int)W, CB, grad_in);
+        hipLaunchKernelGGL((k_roipool_bwd<DG_POOL_AVG, false>), grid, dim3(256), lds, st, grad_out, argmax, win, w.off, w.list, (int)C, (int)H, (int)W, CB, grad_in);
     DG_CHECK_LAUNCH("k_roipool_bwd");
     return DG_OK;
 }

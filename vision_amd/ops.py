@@ -113,31 +113,37 @@ def roi_windows(rois, roi_idx, B, H, W, dev):
     return win, status
 
 
-def to_nhwc(img):
-    """(B,C,H,W) fp32 -> (B,H,W,C) staging copy; free if the tensor is already channels_last."""
+def to_nhwc(img, out=None, nan_flag=None):
+    """(B,C,H,W) fp32 -> ((B,H,W,C) staging copy, nan_flag).  nan_flag is a device int32 that is non-zero iff
+    the map holds a NaN (None for a tensor that already is channels_last: no copy, NaN state unknown)."""
     B, C_, H, W = img.shape
     if img.is_contiguous(memory_format=torch.channels_last) and not img.is_contiguous():
-        return img.permute(0, 2, 3, 1)             # same bytes, viewed NHWC
+        return img.permute(0, 2, 3, 1), None       # same bytes, viewed NHWC
     img = img.contiguous()
-    out = torch.empty((B, H, W, C_), dtype=torch.float32, device=img.device)
+    if out is None:
+        out = torch.empty((B, H, W, C_), dtype=torch.float32, device=img.device)
+    if nan_flag is None:
+        nan_flag = torch.zeros((1,), dtype=torch.int32, device=img.device)
+    else:
+        nan_flag.zero_()
     with torch.cuda.device(img.device):
-        check(load().dg_nchw_to_nhwc_f32(ptr(img), B, C_, H, W, ptr(out), stream_ptr(img.device)))
-    return out
+        check(load().dg_nchw_to_nhwc_f32(ptr(img), B, C_, H, W, ptr(out), ptr(nan_flag), stream_ptr(img.device)))
+    return out, nan_flag
 
 
-def roipool_forward(img, win, mode="max", P=7, out=None, argmax=None, nhwc=None):
+def roipool_forward(img, win, mode="max", P=7, out=None, argmax=None, nhwc=None, nan_flag=None):
     dev = img.device
     B, C_, H, W = img.shape
     n = win.shape[0]
     if nhwc is None:
-        nhwc = to_nhwc(img)
+        nhwc, nan_flag = to_nhwc(img)
     m = _abi.POOL_MAX if mode == "max" else _abi.POOL_AVG
     if out is None:
         out = torch.empty((n, C_, P, P), dtype=torch.float32, device=dev)
     if m == _abi.POOL_MAX and argmax is None:
         argmax = torch.empty((n, C_, P, P), dtype=torch.int32, device=dev)
     with torch.cuda.device(dev):
-        check(load().dg_roipool_fwd_f32(ptr(nhwc), B, C_, H, W, ptr(win), n, P, m, ptr(out),
+        check(load().dg_roipool_fwd_f32(ptr(nhwc), B, C_, H, W, ptr(win), n, P, m, ptr(nan_flag), ptr(out),
                                         ptr(argmax) if m == _abi.POOL_MAX else None, stream_ptr(dev)))
     return out, (argmax if m == _abi.POOL_MAX else None)
 
