@@ -330,6 +330,20 @@ __global__ __launch_bounds__(256) void k_roi_fill(const int32_t *__restrict__ wi
     if (valid) list[start + r] = (int32_t)i;
 }
 
+// LDS float accumulate.  Measured on MI355X (tools/ubench/lds_atomic.hip): a wave-wide LDS f32 atomic add costs
+// ~194 cycles whatever the address pattern, an i32 LDS atomic 5-9 cycles, so the add is built from a plain read
+// and a 32-bit compare-and-swap; it only retries when two lanes really hit the same word.
+__device__ __forceinline__ void lds_fadd(float *p, float g)
+{
+    int *ip = reinterpret_cast<int *>(p);
+    int old = *reinterpret_cast<volatile int *>(ip);
+    while (true) {
+        const int assumed = old;
+        old = atomicCAS(ip, assumed, __float_as_int(__int_as_float(assumed) + g));
+        if (old == assumed) break;
+    }
+}
+
 // grid: x = channel block (CB channels), y = image.  Dynamic LDS: CB*H*W floats.
 // VEC: CB*49 % 4 == 0 and 16-byte aligned tensors -> each thread moves 4 consecutive elements of one RoI
 // (16-byte loads of grad_out and argmax), two such groups in flight per thread.
@@ -363,14 +377,14 @@ __global__ __launch_bounds__(256) void k_roipool_bwd(const float *__restrict__ g
             const float4 gb = *reinterpret_cast<const float4 *>(grad_out + ob);
             const int4 ib = *reinterpret_cast<const int4 *>(argmax + ob);
             const int ea = 4 * qa, eb = 4 * qb;
-            atomicAdd(&plane[((ea + 0) / RBINS) * HW + ia.x], ga.x);
-            atomicAdd(&plane[((ea + 1) / RBINS) * HW + ia.y], ga.y);
-            atomicAdd(&plane[((ea + 2) / RBINS) * HW + ia.z], ga.z);
-            atomicAdd(&plane[((ea + 3) / RBINS) * HW + ia.w], ga.w);
-            atomicAdd(&plane[((eb + 0) / RBINS) * HW + ib.x], gb.x);
-            atomicAdd(&plane[((eb + 1) / RBINS) * HW + ib.y], gb.y);
-            atomicAdd(&plane[((eb + 2) / RBINS) * HW + ib.z], gb.z);
-            atomicAdd(&plane[((eb + 3) / RBINS) * HW + ib.w], gb.w);
+            lds_fadd(&plane[((ea + 0) / RBINS) * HW + ia.x], ga.x);
+            lds_fadd(&plane[((ea + 1) / RBINS) * HW + ia.y], ga.y);
+            lds_fadd(&plane[((ea + 2) / RBINS) * HW + ia.z], ga.z);
+            lds_fadd(&plane[((ea + 3) / RBINS) * HW + ia.w], ga.w);
+            lds_fadd(&plane[((eb + 0) / RBINS) * HW + ib.x], gb.x);
+            lds_fadd(&plane[((eb + 1) / RBINS) * HW + ib.y], gb.y);
+            lds_fadd(&plane[((eb + 2) / RBINS) * HW + ib.z], gb.z);
+            lds_fadd(&plane[((eb + 3) / RBINS) * HW + ib.w], gb.w);
         }
         for (; t < work; t += 256) {
             const int ra = (int)(t / per4), qa = (int)(t - (int64_t)ra * per4);
@@ -378,10 +392,10 @@ __global__ __launch_bounds__(256) void k_roipool_bwd(const float *__restrict__ g
             const float4 ga = *reinterpret_cast<const float4 *>(grad_out + oa);
             const int4 ia = *reinterpret_cast<const int4 *>(argmax + oa);
             const int ea = 4 * qa;
-            atomicAdd(&plane[((ea + 0) / RBINS) * HW + ia.x], ga.x);
-            atomicAdd(&plane[((ea + 1) / RBINS) * HW + ia.y], ga.y);
-            atomicAdd(&plane[((ea + 2) / RBINS) * HW + ia.z], ga.z);
-            atomicAdd(&plane[((ea + 3) / RBINS) * HW + ia.w], ga.w);
+            lds_fadd(&plane[((ea + 0) / RBINS) * HW + ia.x], ga.x);
+            lds_fadd(&plane[((ea + 1) / RBINS) * HW + ia.y], ga.y);
+            lds_fadd(&plane[((ea + 2) / RBINS) * HW + ia.z], ga.z);
+            lds_fadd(&plane[((ea + 3) / RBINS) * HW + ia.w], ga.w);
         }
     } else {
         const int64_t work = (int64_t)(r1 - r0) * per;
@@ -392,7 +406,7 @@ __global__ __launch_bounds__(256) void k_roipool_bwd(const float *__restrict__ g
             const float g = grad_out[o];
             const int ch = e / RBINS;
             if (MODE == DG_POOL_MAX) {
-                atomicAdd(&plane[ch * HW + argmax[o]], g);
+                lds_fadd(&plane[ch * HW + argmax[o]], g);
             } else {
                 const int bin = e - ch * RBINS, ph = bin / RP, pw = bin - ph * RP;
                 const int32_t *w = win + 5 * (int64_t)roi;
@@ -401,7 +415,7 @@ __global__ __launch_bounds__(256) void k_roipool_bwd(const float *__restrict__ g
                 const int ws = x1 + (pw * Lw) / RP, we = x1 + ((pw + 1) * Lw + RP - 1) / RP;
                 const float gd = g / (float)(he - hs) / (float)(we - ws);
                 for (int y = hs; y < he; ++y)
-                    for (int x = ws; x < we; ++x) atomicAdd(&plane[ch * HW + y * W + x], gd);
+                    for (int x = ws; x < we; ++x) lds_fadd(&plane[ch * HW + y * W + x], gd);
             }
         }
     }
