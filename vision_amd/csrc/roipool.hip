@@ -71,8 +71,18 @@ template <bool NANSAFE>
 __device__ __forceinline__ void max_upd(float &best, int &bi, float v, int idx)
 {
     if (NANSAFE) { if ((v > best) || (v != v)) { best = v; bi = idx; } }
-    else         { if (v > best) { best = v; bi = idx; } }
+    else         { bi = (v > best) ? idx : bi; best = fmaxf(best, v); }   // v_max_f32 is full rate, v_cmp/v_cndmask half rate
 }
+
+#ifdef DG_STAMPS
+// diagnostic build only (tools/ubench/roi_fwd_stamps.hip): where a task spends its cycles
+__device__ unsigned long long dg_stamp_acc[8];
+#define STAMP(var) unsigned long long var = __builtin_readcyclecounter()
+#define STAMP_ADD(slot, a, b) stamp_loc[slot] += (b) - (a)
+#else
+#define STAMP(var)
+#define STAMP_ADD(slot, a, b)
+#endif
 
 #define RING_PX 64                       // crop pixels (x 64 channels x 4 B = 16 KiB) resident in LDS per wave
 #define FWD_LDS_FLOATS (64 * RBINS + 64 * RBINS / 2)   // [64][49] f32 values + [64][49] u16 indices = 18,816 B
@@ -84,67 +94,94 @@ __device__ __forceinline__ void max_upd(float &best, int &bi, float v, int idx)
 // per-(bin,j) LDS addresses computed once per task.  All 49 results stay in registers (the 7 strips are
 // unrolled), so the [channel][bin] transpose buffer can alias the ring: 18.8 KB of LDS per wave, 8 waves/CU.
 template <int XW, bool NANSAFE>
-__device__ __forceinline__ void roi_task_staged(char *smem, const float *__restrict__ nhwc, int C, int H, int W, int lane,
-                                                int x1, int y1, int x2, int y2, int b, int c0, int R,
-                                                float (&oval)[RBINS], int (&oidx)[RBINS])
+__device__ __forceinline__ void roi_task_staged(char *smem, const char *__restrict__ imgc0, int pixbytes, int W, int lane,
+                                                int x1, int y1, int x2, int y2, int R,
+                                                float (&oval)[RBINS], int (&oidx)[RBINS]
+#ifdef DG_STAMPS
+                                                , unsigned long long *stamp_loc
+#endif
+                                                )
 {
     const int Lh = y2 - y1, Lw = x2 - x1, Lwp = (Lw + 3) & ~3;
     const int rowbytes = Lwp * 256;
-    int ws[RP], we[RP];
-    int addr[RP][XW];                                   // byte address of (bin, j) inside a ring row, + lane*4
+    // adaptive column-bin edges (uniform -> scalar registers) and the byte offset of (bin, j) inside a ring row
+    int ws[RP], we[RP], soff[RP][XW];
 #pragma unroll
     for (int i = 0; i < RP; ++i) {
         ws[i] = (i * Lw) / RP;                          // relative to x1
         we[i] = ((i + 1) * Lw + RP - 1) / RP;
 #pragma unroll
-        for (int j = 0; j < XW; ++j) addr[i][j] = min(ws[i] + j, we[i] - 1) * 256 + lane * 4;
+        for (int j = 0; j < XW; ++j) soff[i][j] = min(ws[i] + j, we[i] - 1) * 256 + lane * 4;   // per-lane (VGPR)
     }
-    // LDS-DMA source: this lane moves channel quad (lane & 15) of pixel (lane >> 4) of each group of 4 pixels
-    const char *gq = (const char *)(nhwc + ((int64_t)b * H * W) * C + c0 + (lane & 15) * 4);
+    // LDS-DMA source offsets: this lane moves channel quad (lane & 15) of pixel (lane >> 4) of each group of 4 pixels
     const int pxl = lane >> 4;
-    const int64_t pixbytes = (int64_t)C * 4;
+    unsigned voff[6];                                   // Lwp <= 24
+#pragma unroll
+    for (int q = 0; q < 6; ++q) voff[q] = (unsigned)(min(4 * q + pxl, Lw - 1) * pixbytes + (lane & 15) * 16);
+    const int nq = Lwp >> 2;
     int loaded = y1, lslot = 0;
     auto issue_rows = [&](int ylimit) {
-        for (; loaded < ylimit; ++loaded) {
-            const char *rowg = gq + ((int64_t)loaded * W + x1) * pixbytes;
+        while (loaded < ylimit) {
+            const char *rowg = imgc0 + (int64_t)(loaded * W + x1) * pixbytes;      // uniform
             char *rowl = smem + lslot * rowbytes;
-            for (int q = 0; q < Lwp; q += 4) {
-                const int px = min(q + pxl, Lw - 1);
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rowg + px * pixbytes),
-                                                 (__attribute__((address_space(3))) void *)(rowl + q * 256), 16, 0, 0);
-            }
+#pragma unroll
+            for (int q = 0; q < 6; ++q)
+                if (q < nq)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rowg + voff[q]),
+                                                     (__attribute__((address_space(3))) void *)(rowl + q * 1024), 16, 0, 0);
             lslot = (lslot + 1 == R) ? 0 : lslot + 1;
+            ++loaded;
         }
     };
+    STAMP(tp0);
     issue_rows(min(y2, y1 + R));
+    STAMP(tp1);
+    STAMP_ADD(0, tp0, tp1);
+    int slot = 0, prev_hs = y1;
 #pragma unroll
     for (int ph = 0; ph < RP; ++ph) {
         const int hs = y1 + (ph * Lh) / RP, he = y1 + ((ph + 1) * Lh + RP - 1) / RP;
+        STAMP(t0);
         issue_rows(he);                                    // normally already issued
+        STAMP(t1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // rows < he have landed
+        STAMP(t2);
         issue_rows(min(y2, hs + R));                       // prefetch; only overwrites rows < hs
+        STAMP(t3);
+        STAMP_ADD(0, t0, t1); STAMP_ADD(1, t1, t2); STAMP_ADD(0, t2, t3);
+        slot += hs - prev_hs;                              // hs advances by <= maxrows <= R
+        if (slot >= R) slot -= R;
+        prev_hs = hs;
         float best[RP];
-        int code[RP];                                      // (row in strip) * 8 + j of the current maximum
+        int code[RP];
 #pragma unroll
         for (int i = 0; i < RP; ++i) { best[i] = -INFINITY; code[i] = 0; }
-        int slot = (hs - y1) % R;
-        int rowoff = slot * rowbytes;
+        int sl = slot, so = slot * rowbytes;
+        // code of the running maximum.  NaN-free maps: r*W + j (a clamped re-read can never win a strict >, so the
+        // index is base + code); NaN-exact: r*8 + j, decoded with the clamp.
+        int rcode = 0;
         for (int r = 0; r < he - hs; ++r) {
 #pragma unroll
             for (int j = 0; j < XW; ++j) {
-                const int cj = r * 8 + j;
+                const int cj = rcode + j;
 #pragma unroll
                 for (int i = 0; i < RP; ++i)
-                    max_upd<NANSAFE>(best[i], code[i], *(const float *)(smem + (addr[i][j] + rowoff)), cj);
+                    max_upd<NANSAFE>(best[i], code[i], *(const float *)(smem + (soff[i][j] + so)), cj);
             }
-            rowoff += rowbytes;
-            if (++slot == R) { slot = 0; rowoff = 0; }
+            rcode += NANSAFE ? 8 : W;
+            so += rowbytes;
+            if (++sl == R) { sl = 0; so = 0; }
         }
+        STAMP(t4);
+        const int ibase = hs * W + x1;
 #pragma unroll
         for (int i = 0; i < RP; ++i) {
             oval[ph * RP + i] = best[i];
-            oidx[ph * RP + i] = (hs + (code[i] >> 3)) * W + x1 + min(ws[i] + (code[i] & 7), we[i] - 1);
+            if (NANSAFE) oidx[ph * RP + i] = ibase + (code[i] >> 3) * W + min(ws[i] + (code[i] & 7), we[i] - 1);
+            else oidx[ph * RP + i] = ibase + ws[i] + code[i];
         }
+        STAMP(t5);
+        STAMP_ADD(2, t3, t4); STAMP_ADD(3, t4, t5);
     }
 }
 
@@ -159,6 +196,10 @@ __global__ __launch_bounds__(64) void k_roipool_fwd(const float *__restrict__ nh
     unsigned short *sidx = reinterpret_cast<unsigned short *>(smemf + 64 * RBINS);
     const int lane = threadIdx.x;
     const bool may_nan = nan_flag ? (__builtin_amdgcn_readfirstlane(nan_flag[0]) != 0) : true;
+#ifdef DG_STAMPS
+    unsigned long long stamp_loc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    STAMP(tk0);
+#endif
     // Persistent single-wave workgroups.  Task = (RoI, 64-channel block), channel block fastest; the grid is a
     // multiple of 8, so a workgroup (and the XCD it sits on, blockIdx % 8) keeps one channel slice of the map.
 #pragma unroll 1
@@ -173,38 +214,49 @@ __global__ __launch_bounds__(64) void k_roipool_fwd(const float *__restrict__ nh
         const int Lh = y2 - y1, Lw = x2 - x1;
         const int cvalid = (C - c0) < 64 ? (C - c0) : 64;
 
+        STAMP(ta);
         bool staged = false;
         if (MODE == DG_POOL_MAX) {
             const int Lwp = (Lw + 3) & ~3;
             const int R = RING_PX / Lwp;
-            int maxw = 0, maxrows = 0;                                     // widest / tallest adaptive bin
-#pragma unroll
-            for (int i = 0; i < RP; ++i) {
-                maxw = max(maxw, ((i + 1) * Lw + RP - 1) / RP - (i * Lw) / RP);
-                maxrows = max(maxrows, ((i + 1) * Lh + RP - 1) / RP - (i * Lh) / RP);
-            }
-            staged = (R >= maxrows) && (maxw <= 4) && (maxrows <= 8) && (cvalid == 64) && ((C & 3) == 0) &&
-                     ((((uintptr_t)nhwc) & 15) == 0);
+            // widest / tallest adaptive bin of a length L = 7q + r: q (r == 0), q + 1 (r == 1), q + 2 (r >= 2)
+            const int qw = Lw / RP, rw = Lw - qw * RP, qh = Lh / RP, rh = Lh - qh * RP;
+            const int maxw = qw + (rw > 1 ? 2 : rw), maxrows = qh + (rh > 1 ? 2 : rh);
+            staged = (R >= maxrows) && (maxw <= 4) && (Lwp <= 24) && (cvalid == 64) && ((C & 3) == 0) &&
+                     ((((uintptr_t)nhwc) & 15) == 0) && ((int64_t)H * W * C * 4 < (1ll << 31));
             if (staged) {
                 float oval[RBINS];
                 int oidx[RBINS];
                 char *smem = reinterpret_cast<char *>(smemf);
+#ifdef DG_STAMPS
+#define STAMP_ARG , stamp_loc
+#else
+#define STAMP_ARG
+#endif
+                const char *imgc0 = reinterpret_cast<const char *>(nhwc + ((int64_t)b * H * W) * C + c0);
 #define STAGED(XWV)                                                                                                         \
-    if (may_nan) roi_task_staged<XWV, true>(smem, nhwc, C, H, W, lane, x1, y1, x2, y2, b, c0, R, oval, oidx);               \
-    else roi_task_staged<XWV, false>(smem, nhwc, C, H, W, lane, x1, y1, x2, y2, b, c0, R, oval, oidx)
+    if (may_nan) roi_task_staged<XWV, true>(smem, imgc0, C * 4, W, lane, x1, y1, x2, y2, R, oval, oidx STAMP_ARG);          \
+    else roi_task_staged<XWV, false>(smem, imgc0, C * 4, W, lane, x1, y1, x2, y2, R, oval, oidx STAMP_ARG)
+#ifdef DG_ONEVARIANT
+                roi_task_staged<4, false>(smem, imgc0, C * 4, W, lane, x1, y1, x2, y2, R, oval, oidx STAMP_ARG);
+#else
                 switch (maxw) {
                 case 1: STAGED(1); break;
                 case 2: STAGED(2); break;
                 case 3: STAGED(3); break;
                 default: STAGED(4); break;
                 }
+#endif
 #undef STAGED
+                STAMP(tw0);
                 // all ring reads are done (results are in registers): the transpose buffer may overwrite the ring
 #pragma unroll
                 for (int i = 0; i < RBINS; ++i) {
                     sval[lane * RBINS + i] = oval[i];
                     sidx[lane * RBINS + i] = (unsigned short)oidx[i];
                 }
+                STAMP(tw1);
+                STAMP_ADD(7, tw0, tw1);
             }
         }
         if (!staged) {
@@ -246,16 +298,48 @@ __global__ __launch_bounds__(64) void k_roipool_fwd(const float *__restrict__ nh
                 }
             }
         }
+        STAMP(tb);
         __syncthreads();
         // contiguous run of cvalid*49 outputs for this (roi, channel block)
         const int64_t obase = (roi * C + c0) * RBINS;
         const int total = cvalid * RBINS;
         if (vec_ok) {
-            for (int e = lane * 4; e < total; e += 256) {
-                *reinterpret_cast<float4 *>(out + obase + e) = *reinterpret_cast<const float4 *>(sval + e);
+            // 64*49/4 = 784 16-byte pieces = 12.25 wave-wide rounds; reads of a batch are issued before its stores
+            if (cvalid == 64) {
+                const float *sv = sval + lane * 4;
+                const unsigned short *si = sidx + lane * 4;
+                float *go = out + obase + lane * 4;
+                int32_t *ga = argmax + obase + lane * 4;
+#pragma unroll
+                for (int h = 0; h < 12; h += 6) {
+                    float4 v[6];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) v[k] = *reinterpret_cast<const float4 *>(sv + (h + k) * 256);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) *reinterpret_cast<float4 *>(go + (h + k) * 256) = v[k];
+                }
+                if (lane < 16) *reinterpret_cast<float4 *>(go + 12 * 256) = *reinterpret_cast<const float4 *>(sv + 12 * 256);
                 if (MODE == DG_POOL_MAX && argmax) {
-                    const ushort4 u = *reinterpret_cast<const ushort4 *>(sidx + e);
-                    *reinterpret_cast<int4 *>(argmax + obase + e) = make_int4(u.x, u.y, u.z, u.w);
+#pragma unroll
+                    for (int h = 0; h < 12; h += 6) {
+                        ushort4 u[6];
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) u[k] = *reinterpret_cast<const ushort4 *>(si + (h + k) * 256);
+#pragma unroll
+                        for (int k = 0; k < 6; ++k) *reinterpret_cast<int4 *>(ga + (h + k) * 256) = make_int4(u[k].x, u[k].y, u[k].z, u[k].w);
+                    }
+                    if (lane < 16) {
+                        const ushort4 u = *reinterpret_cast<const ushort4 *>(si + 12 * 256);
+                        *reinterpret_cast<int4 *>(ga + 12 * 256) = make_int4(u.x, u.y, u.z, u.w);
+                    }
+                }
+            } else {
+                for (int e = lane * 4; e < total; e += 256) {
+                    *reinterpret_cast<float4 *>(out + obase + e) = *reinterpret_cast<const float4 *>(sval + e);
+                    if (MODE == DG_POOL_MAX && argmax) {
+                        const ushort4 u = *reinterpret_cast<const ushort4 *>(sidx + e);
+                        *reinterpret_cast<int4 *>(argmax + obase + e) = make_int4(u.x, u.y, u.z, u.w);
+                    }
                 }
             }
         } else {
@@ -265,7 +349,15 @@ __global__ __launch_bounds__(64) void k_roipool_fwd(const float *__restrict__ nh
             }
         }
         __syncthreads();      // the buffer is reused by the next task's ring
+        STAMP(tc);
+        STAMP_ADD(4, ta, tb); STAMP_ADD(5, tb, tc);
     }
+#ifdef DG_STAMPS
+    STAMP(tk1);
+    STAMP_ADD(6, tk0, tk1);
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&dg_stamp_acc[i], stamp_loc[i]);
+#endif
 }
 
 // ---------------------------------------------------------------- backward: per-image RoI lists
