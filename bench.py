@@ -81,10 +81,10 @@ class Dist:
 # ------------------------------------------------------------------ config 3 (primary) / config 1
 class FrcnnBatch:
     def __init__(self, d, images_total, n_rois=2000, C=512, H=38, W=50, nms_thr=0.7):
-        from vision_amd import ops, workloads as wl
+        from vision_amd import ops, shard, workloads as wl
         self.ops, self.d = ops, d
-        per = images_total // d.world
-        first = d.rank * per
+        first, last = shard.shard_range(images_total, d.rank, d.world)     # contiguous image range of this rank
+        per = last - first
         self.B, self.n_rois, self.shape = per, n_rois, (per, C, H, W)
         dev = d.dev
         g = torch.Generator(device=dev).manual_seed(1234 + d.rank)
@@ -133,7 +133,7 @@ class FrcnnBatch:
         assert int(self.status.item()) == 0, "empty RoI in synthetic workload"
 
 
-def cpu_baseline_frcnn(images=2, n_rois=2000):
+def cpu_baseline_frcnn(images=12, n_rois=2000):
     """CPU oracle (scalar C port of the reference algorithm), one core, same step on a bounded sample."""
     from oracle import oracle as orc
     from vision_amd import workloads as wl
@@ -220,19 +220,19 @@ def extra_stress(d, n=65536):
 
 
 def extra_kmeans(d, n_total=10_000_000, iters=30):
-    from vision_amd import cluster, workloads as wl
-    per = n_total // d.world
+    from vision_amd import cluster, shard as sh, workloads as wl
     wh_all = wl.anchor_wh(0, n_total)
     init = cluster.kmean.init_centers(wh_all, 5, 42)
-    shard = torch.from_numpy(wh_all[d.rank * per:(d.rank + 1) * per]).to(d.dev)
+    lo, hi = sh.shard_range(n_total, d.rank, d.world)
+    per = hi - lo
+    shard = torch.from_numpy(wh_all[lo:hi]).to(d.dev)
     del wh_all
     km = cluster.kmean(5, 42)
     km.fit(shard, init_centers=init, fixed_iters=3)          # warm-up (RCCL channels, workspace)
     sec = Dist.timed(d, lambda: km.fit(shard, init_centers=init, fixed_iters=iters), 1, 0)
     # kernel-only rate of the step on this shard
-    wh, cent, labels, acc = km._dev_state
-    from vision_amd import ops
-    ms = ev_time(lambda: ops.kmeans_step(wh, cent, labels, acc), 20, 3)
+    be = km._backend
+    ms = ev_time(be.step, 20, 3)
     return {"iters_per_s": iters / sec, "ms_per_iter": sec / iters * 1e3, "boxes_total": n_total, "ranks": d.world,
             "step_kernel_ms_per_shard": ms, "step_hbm_frac": (12.0 * per) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             "centers": km.cluster_centers_.round(6).tolist(),
@@ -256,7 +256,7 @@ def main():
     w = FrcnnBatch(d, a.images)
     sec = d.timed(w.step, a.steps, a.warmup)
     w.check()
-    total_rois = a.images // d.world * d.world * w.n_rois
+    total_rois = a.images * w.n_rois
     ms_step = sec / a.steps * 1e3
     value = total_rois * a.steps / sec
 

@@ -129,6 +129,9 @@ int dg_kmeans_iou_step(const float *wh, int64_t n, const float *cent, int64_t k,
 /* centroid = sum/count (int64 fixed point 2^32 -> fp32); empty cluster keeps its centroid.
  * history (may be NULL): history[slot] = acc[3k] (changed count of this iteration). */
 int dg_kmeans_update(const int64_t *acc, int64_t k, float *cent, int64_t *history, int64_t slot, dg_stream_t s);
+/* `iters` iterations of step+update back to back on ONE device (no all-reduce): history[slot0+t] = changed count. */
+int dg_kmeans_iou_run(const float *wh, int64_t n, float *cent, int64_t k, uint8_t *labels, int64_t *acc,
+                      int64_t *history, int64_t slot0, int64_t iters, void *ws, size_t ws_bytes, dg_stream_t s);
 int dg_kmeans_labels_i32(const uint8_t *labels, int64_t n, int32_t *out, dg_stream_t s);
 
 /* ---------------------------------------------------------------- R-CNN box regression ("next" rows)

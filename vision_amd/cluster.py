@@ -16,13 +16,41 @@ from . import _abi, ops
 _CHUNK = 8          # iterations launched between two host checks of the changed-count history
 
 
+class _HipBackend:
+    """Device side of the Lloyd loop: HIP kernels through the C ABI (the only backend the product has)."""
+
+    def prepare(self, X, init_centers, k, iters):
+        dev = _abi.device_of(X)
+        self.wh = _abi.to_dev(X, torch.float32, dev).reshape(-1, 2)
+        self.cent = _abi.to_dev(np.asarray(init_centers, np.float32), torch.float32, dev).reshape(k, 2).clone()
+        self.labels = torch.full((self.wh.shape[0],), 255, dtype=torch.uint8, device=dev)
+        self.acc = torch.zeros(3 * k + 2, dtype=torch.int64, device=dev)
+        self.history = torch.zeros(max(iters, 1), dtype=torch.int64, device=dev)
+
+    def run_local(self, slot0, iters):
+        ops.kmeans_run(self.wh, self.cent, self.labels, self.acc, self.history, slot0, iters)
+
+    def step(self):
+        ops.kmeans_step(self.wh, self.cent, self.labels, self.acc)
+
+    def update(self, slot):
+        ops.kmeans_update(self.acc, self.cent, self.history, slot)
+
+    def history_host(self, upto):
+        return self.history[:upto].cpu().numpy()
+
+    def results(self):
+        return (self.cent.cpu().numpy(), ops.kmeans_labels_i32(self.labels).cpu().numpy(), self.acc.cpu().numpy())
+
+
 class kmean:
     def __init__(self, n_clusters=5, random_state=42, max_iter=300, group=None, reduce_device=None):
         if not 1 <= n_clusters <= 16:
             raise ValueError("n_clusters must be in [1,16]")
         self.n_clusters, self.random_state, self.max_iter = n_clusters, random_state, max_iter
         self.group = group
-        self.reduce_device = reduce_device      # tests: all-reduce on CPU (gloo) while kernels run on the GPU
+        self.reduce_device = reduce_device      # all-reduce on another device (e.g. "cpu" with gloo)
+        self._backend = _HipBackend()
         self.cluster_centers_ = None
         self.labels_ = None
         self.n_iter_ = 0
@@ -53,41 +81,38 @@ class kmean:
     def fit(self, X, init_centers=None, fixed_iters=None):
         """X: this rank's shard, (n,2) w,h in (0,1].  With more than one rank pass `init_centers`
         (computed from the full set, e.g. kmean.init_centers on rank 0 and broadcast)."""
-        dev = _abi.device_of(X)
-        wh = _abi.to_dev(X, torch.float32, dev).reshape(-1, 2)
         k = self.n_clusters
         if init_centers is None:
             if self._world() > 1:
                 raise ValueError("sharded fit needs init_centers drawn from the full box set")
             src = X.cpu().numpy() if isinstance(X, torch.Tensor) else X
             init_centers = self.init_centers(src, k, self.random_state)
-        cent = _abi.to_dev(np.asarray(init_centers, np.float32), torch.float32, dev).reshape(k, 2).clone()
-        labels = torch.full((wh.shape[0],), 255, dtype=torch.uint8, device=dev)
-        acc = torch.zeros(3 * k + 2, dtype=torch.int64, device=dev)
         iters = fixed_iters if fixed_iters is not None else self.max_iter
-        history = torch.zeros(max(iters, 1), dtype=torch.int64, device=dev)
+        be = self._backend
+        be.prepare(X, init_centers, k, iters)
         done, n_iter = 0, 0
         while done < iters:
             chunk = min(_CHUNK if fixed_iters is None else iters, iters - done)
-            for j in range(chunk):
-                ops.kmeans_step(wh, cent, labels, acc)
-                self._allreduce(acc)
-                # a converged iteration (changed == 0) recomputes identical centroids, so running the
-                # rest of the chunk is idempotent; n_iter_ is read from the history afterwards.
-                ops.kmeans_update(acc, cent, history, done + j)
+            # a converged iteration (changed == 0) recomputes identical centroids, so running the
+            # rest of the chunk is idempotent; n_iter_ is read from the history afterwards.
+            if self._world() == 1:
+                be.run_local(done, chunk)
+            else:
+                for j in range(chunk):
+                    be.step()
+                    self._allreduce(be.acc)
+                    be.update(done + j)
             done += chunk
             n_iter = done
             if fixed_iters is None:
-                h = history[:done].cpu().numpy()
-                z = np.nonzero(h == 0)[0]
+                z = np.nonzero(be.history_host(done) == 0)[0]
                 if z.size:
                     n_iter = int(z[0]) + 1
                     break
-        self.cluster_centers_ = cent.cpu().numpy()
-        self.labels_ = ops.kmeans_labels_i32(labels).cpu().numpy()
+        cent, labels, acc = be.results()
+        self.cluster_centers_, self.labels_ = cent, labels
         self.n_iter_ = n_iter
-        self.inertia_ = float(acc[3 * k + 1].item()) / 4294967296.0
-        self._dev_state = (wh, cent, labels, acc)
+        self.inertia_ = float(acc[3 * k + 1]) / 4294967296.0
         return self
 
     def fit_predict(self, X, **kw):

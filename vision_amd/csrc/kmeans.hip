@@ -174,6 +174,22 @@ extern "C" int dg_kmeans_update(const int64_t *acc, int64_t k, float *cent, int6
     return DG_OK;
 }
 
+// `iters` Lloyd iterations back to back on one device (step + finish + update per iteration, no host round trip);
+// history[slot0 + t] = changed count of iteration t.  A converged iteration reproduces the same centroids, so
+// running past convergence is idempotent and n_iter_ is read from the history afterwards.
+extern "C" int dg_kmeans_iou_run(const float *wh, int64_t n, float *cent, int64_t k, uint8_t *labels, int64_t *acc,
+                                 int64_t *history, int64_t slot0, int64_t iters, void *ws, size_t ws_bytes, dg_stream_t s)
+{
+    DG_REQUIRE(iters >= 0, "kmeans_run: iters < 0");
+    for (int64_t t = 0; t < iters; ++t) {
+        int rc = dg_kmeans_iou_step(wh, n, cent, k, labels, acc, ws, ws_bytes, s);
+        if (rc) return rc;
+        rc = dg_kmeans_update(acc, k, cent, history, slot0 + t, s);
+        if (rc) return rc;
+    }
+    return DG_OK;
+}
+
 extern "C" int dg_kmeans_labels_i32(const uint8_t *labels, int64_t n, int32_t *out, dg_stream_t s)
 {
     DG_REQUIRE(n >= 0, "kmeans_labels: n < 0");

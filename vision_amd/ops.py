@@ -175,6 +175,17 @@ def kmeans_step(wh, cent, labels, acc):
     return acc
 
 
+def kmeans_run(wh, cent, labels, acc, history, slot0, iters):
+    """iters Lloyd iterations on one device without returning to Python in between."""
+    dev = wh.device
+    n, k = wh.shape[0], cent.shape[0]
+    nbytes = load().dg_kmeans_workspace_bytes(n, k)
+    ws = workspace(dev, nbytes)
+    with torch.cuda.device(dev):
+        check(load().dg_kmeans_iou_run(ptr(wh), n, ptr(cent), k, ptr(labels), ptr(acc), ptr(history), slot0, iters, ptr(ws), nbytes,
+                                       stream_ptr(dev)))
+
+
 def kmeans_update(acc, cent, history=None, slot=0):
     dev = cent.device
     with torch.cuda.device(dev):
