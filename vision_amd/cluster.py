@@ -95,13 +95,7 @@ class kmean:
             chunk = min(_CHUNK if fixed_iters is None else iters, iters - done)
             # a converged iteration (changed == 0) recomputes identical centroids, so running the
             # rest of the chunk is idempotent; n_iter_ is read from the history afterwards.
-            if self._world() == 1:
-                be.run_local(done, chunk)
-            else:
-                for j in range(chunk):
-                    be.step()
-                    self._allreduce(be.acc)
-                    be.update(done + j)
+            self._run_iters(done, chunk)
             done += chunk
             n_iter = done
             if fixed_iters is None:
@@ -114,6 +108,17 @@ class kmean:
         self.n_iter_ = n_iter
         self.inertia_ = float(acc[3 * k + 1]) / 4294967296.0
         return self
+
+    def _run_iters(self, slot0, count):
+        """`count` Lloyd iterations, asynchronous on the current stream (history slots slot0..)."""
+        be = self._backend
+        if self._world() == 1:
+            be.run_local(slot0, count)
+        else:
+            for j in range(count):
+                be.step()
+                self._allreduce(be.acc)
+                be.update(slot0 + j)
 
     def fit_predict(self, X, **kw):
         return self.fit(X, **kw).labels_

@@ -89,27 +89,22 @@ __global__ __launch_bounds__(KM_BLOCK) void k_kmeans_step(const float2 *__restri
     }
 }
 
-// folds the per-workgroup rows (layout with KMAX columns) into acc (layout with k columns)
+// folds the per-workgroup rows (layout with KMAX columns) into acc (layout with k columns); one workgroup per column
 __global__ __launch_bounds__(256) void k_kmeans_finish(const long long *__restrict__ partials, int nblocks, int KMAX, int k,
                                                        long long *__restrict__ acc)
 {
-    __shared__ long long red[256];
-    const int cols = 3 * KMAX + 2;
-    for (int col = 0; col < cols; ++col) {
-        long long v = 0;
-        for (int r = threadIdx.x; r < nblocks; r += 256) v += partials[(int64_t)r * cols + col];
-        red[threadIdx.x] = v;
-        __syncthreads();
-        for (int d = 128; d > 0; d >>= 1) {
-            if (threadIdx.x < d) red[threadIdx.x] += red[threadIdx.x + d];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) {
-            int grp = col / KMAX, c = col - grp * KMAX;
-            if (grp < 3) { if (c < k) acc[grp * k + c] = red[0]; }
-            else acc[3 * k + c] = red[0];           // changed, inertia
-        }
-        __syncthreads();
+    __shared__ long long red[4];
+    const int cols = 3 * KMAX + 2, col = blockIdx.x;
+    long long v = 0;
+    for (int r = threadIdx.x; r < nblocks; r += 256) v += partials[(int64_t)r * cols + col];
+    v = wave_sum_ll(v);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const long long t = (red[0] + red[1]) + (red[2] + red[3]);
+        const int grp = col / KMAX, c = col - grp * KMAX;
+        if (grp < 3) { if (c < k) acc[grp * k + c] = t; }
+        else acc[3 * k + c] = t;                    // changed, inertia
     }
 }
 
@@ -160,7 +155,7 @@ extern "C" int dg_kmeans_iou_step(const float *wh, int64_t n, const float *cent,
         hipLaunchKernelGGL((k_kmeans_step<9>), dim3(nb), dim3(KM_BLOCK), 0, st, (const float2 *)wh, n, cent, (int)k, labels, partials);
     else
         hipLaunchKernelGGL((k_kmeans_step<16>), dim3(nb), dim3(KM_BLOCK), 0, st, (const float2 *)wh, n, cent, (int)k, labels, partials);
-    hipLaunchKernelGGL(k_kmeans_finish, dim3(1), dim3(256), 0, st, partials, nb, kmax, (int)k, (long long *)acc);
+    hipLaunchKernelGGL(k_kmeans_finish, dim3(3 * kmax + 2), dim3(256), 0, st, partials, nb, kmax, (int)k, (long long *)acc);
     DG_CHECK_LAUNCH("k_kmeans_step");
     return DG_OK;
 }

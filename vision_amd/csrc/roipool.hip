@@ -452,7 +452,11 @@ __global__ __launch_bounds__(256) void k_roipool_bwd(const float *__restrict__ g
     const int HW = H * W;
     for (int i = tid; i < cb * HW; i += 256) plane[i] = 0.f;
     __syncthreads();
-    const int r0 = off[b], r1 = off[b + 1];
+    // gridDim.z > 1 (few images): the image's RoI list is split over z, every part adds its LDS slice into a
+    // pre-zeroed grad_in with global float atomics (contiguous 256-byte wave accesses)
+    const int rlo = off[b], rhi = off[b + 1];
+    const int rchunk = (rhi - rlo + (int)gridDim.z - 1) / (int)gridDim.z;
+    const int r0 = min(rhi, rlo + (int)blockIdx.z * rchunk), r1 = min(rhi, r0 + rchunk);
     const int per = cb * RBINS;                      // contiguous elements per RoI for this channel slice
     if (MODE == DG_POOL_MAX && VEC) {
         const int per4 = per >> 2;                   // float4 groups per RoI
@@ -513,7 +517,11 @@ __global__ __launch_bounds__(256) void k_roipool_bwd(const float *__restrict__ g
     }
     __syncthreads();
     float *gi = grad_in + ((int64_t)b * C + c0) * HW;
-    for (int i = tid; i < cb * HW; i += 256) gi[i] = plane[i];
+    if (gridDim.z == 1) {
+        for (int i = tid; i < cb * HW; i += 256) gi[i] = plane[i];
+    } else {
+        for (int i = tid; i < cb * HW; i += 256) atomicAdd(&gi[i], plane[i]);
+    }
 }
 
 // ---------------------------------------------------------------- C ABI
@@ -610,8 +618,11 @@ extern "C" int dg_roipool_bwd_f32(const float *grad_out, const int32_t *argmax, 
     int CB = 1;
     while (CB < 4 && (int64_t)CB * 2 * HW * 4 <= 32 * 1024 && CB * 2 <= C) CB *= 2;      // 4 channels: 16-byte vector path
     while (CB < 16 && (int64_t)CB * 2 * HW * 4 <= 32 * 1024 && B * dg_cdiv(C, CB * 2) >= 1024) CB *= 2;
-    dim3 grid((unsigned)dg_cdiv(C, CB), (unsigned)B);
+    int64_t S = 1;                                     // RoI-list splits when there are too few (image, slice) pairs
+    while (S < 16 && B * dg_cdiv(C, CB) * S < 1024 && n / (B * S * 2) >= 64) S *= 2;
+    dim3 grid((unsigned)dg_cdiv(C, CB), (unsigned)B, (unsigned)S);
     size_t lds = (size_t)CB * HW * 4;
+    if (S > 1 && hipMemsetAsync(grad_in, 0, (size_t)B * C * HW * 4, st) != hipSuccess) { dg_set_error("roipool_bwd: memset failed"); return DG_EHIP; }
     // vector path: every channel slice is whole groups of 4 elements and 16-byte aligned
     const bool vec = mode == DG_POOL_MAX && CB % 4 == 0 && C % CB == 0 &&
                      ((((uintptr_t)grad_out) | ((uintptr_t)argmax)) & 15) == 0;
