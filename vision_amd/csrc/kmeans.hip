@@ -26,54 +26,89 @@ __device__ __forceinline__ long long wave_sum_ll(long long v)
     return v;
 }
 
+// Per-lane accumulators live in LDS ([cluster][w|h][thread] u64 + [cluster][thread] u32): integer LDS atomics to
+// a lane-private word cost ~6 LDS cycles and run beside the VALU, where 3*k predicated 64-bit register adds
+// (half-rate v_cndmask) were the larger half of the kernel.  Addresses differ only by multiples of 2 KiB between
+// clusters, so every wave access is conflict-free whatever the labels are.
+template <int KMAX>
+__device__ __forceinline__ void km_one(float w, float h, const float (&cw)[KMAX], const float (&ch)[KMAX], int k,
+                                       unsigned long long *sacc, unsigned *scnt, long long &inertia, int &changed,
+                                       uint8_t *lab)
+{
+    int best = 0;
+    float bd = kdist(w, h, cw[0], ch[0]);
+#pragma unroll
+    for (int c = 1; c < KMAX; ++c) {
+        if (c < k) {
+            float d = kdist(w, h, cw[c], ch[c]);
+            if (d < bd) { bd = d; best = c; }
+        }
+    }
+    atomicAdd(&sacc[(best * 2 + 0) * KM_BLOCK], (unsigned long long)fx32(w));
+    atomicAdd(&sacc[(best * 2 + 1) * KM_BLOCK], (unsigned long long)fx32(h));
+    atomicAdd(&scnt[best * KM_BLOCK], 1u);
+    inertia += fx32(bd);
+    changed += (*lab != (uint8_t)best);
+    *lab = (uint8_t)best;
+}
+
 template <int KMAX>
 __global__ __launch_bounds__(KM_BLOCK) void k_kmeans_step(const float2 *__restrict__ wh, int64_t n, const float *__restrict__ cent,
                                                           int k, uint8_t *__restrict__ labels, long long *__restrict__ partials)
 {
+    __shared__ unsigned long long sacc_all[KMAX * 2 * KM_BLOCK];
+    __shared__ unsigned scnt_all[KMAX * KM_BLOCK];
+    __shared__ long long red[KM_BLOCK / 64][3 * KMAX + 2];
+    const int tid = threadIdx.x;
     float cw[KMAX], ch[KMAX];
 #pragma unroll
     for (int c = 0; c < KMAX; ++c) {
         cw[c] = (c < k) ? cent[2 * c] : 0.f;
         ch[c] = (c < k) ? cent[2 * c + 1] : 0.f;
+        sacc_all[(c * 2 + 0) * KM_BLOCK + tid] = 0;
+        sacc_all[(c * 2 + 1) * KM_BLOCK + tid] = 0;
+        scnt_all[c * KM_BLOCK + tid] = 0;
     }
-    long long sw[KMAX], sh[KMAX];
-    int cnt[KMAX];
-#pragma unroll
-    for (int c = 0; c < KMAX; ++c) { sw[c] = 0; sh[c] = 0; cnt[c] = 0; }
+    unsigned long long *sacc = sacc_all + tid;     // lane-private column: no barrier needed until the final reduce
+    unsigned *scnt = scnt_all + tid;
     long long inertia = 0;
     int changed = 0;
 
+    // two boxes per lane per 16-byte load, two loads in flight; an 8-byte-aligned shard start is peeled off first
+    const int head = ((reinterpret_cast<uintptr_t>(wh) & 8) && n > 0) ? 1 : 0;
+    if (head && blockIdx.x == 0 && tid == 0) {
+        const float2 a = wh[0];
+        km_one<KMAX>(a.x, a.y, cw, ch, k, sacc, scnt, inertia, changed, labels);
+    }
+    wh += head; n -= head;
+    const int64_t npair = n >> 1;
+    const float4 *wh4 = reinterpret_cast<const float4 *>(wh);
+    uint8_t *lab = labels + head;
     const int64_t stride = (int64_t)gridDim.x * KM_BLOCK;
-    for (int64_t i = (int64_t)blockIdx.x * KM_BLOCK + threadIdx.x; i < n; i += stride) {
-        const float2 b = wh[i];
-        int best = 0;
-        float bd = kdist(b.x, b.y, cw[0], ch[0]);
-#pragma unroll
-        for (int c = 1; c < KMAX; ++c) {
-            if (c < k) {
-                float d = kdist(b.x, b.y, cw[c], ch[c]);
-                if (d < bd) { bd = d; best = c; }
-            }
-        }
-        const long long fw = fx32(b.x), fh = fx32(b.y);
-#pragma unroll
-        for (int c = 0; c < KMAX; ++c) {
-            const bool m = (best == c);
-            sw[c] += m ? fw : 0ll;
-            sh[c] += m ? fh : 0ll;
-            cnt[c] += m ? 1 : 0;
-        }
-        inertia += fx32(bd);
-        changed += (labels[i] != (uint8_t)best);
-        labels[i] = (uint8_t)best;
+    int64_t i = (int64_t)blockIdx.x * KM_BLOCK + tid;
+    for (; i + stride < npair; i += 2 * stride) {
+        const float4 a = wh4[i], b = wh4[i + stride];
+        km_one<KMAX>(a.x, a.y, cw, ch, k, sacc, scnt, inertia, changed, lab + 2 * i);
+        km_one<KMAX>(a.z, a.w, cw, ch, k, sacc, scnt, inertia, changed, lab + 2 * i + 1);
+        km_one<KMAX>(b.x, b.y, cw, ch, k, sacc, scnt, inertia, changed, lab + 2 * (i + stride));
+        km_one<KMAX>(b.z, b.w, cw, ch, k, sacc, scnt, inertia, changed, lab + 2 * (i + stride) + 1);
+    }
+    for (; i < npair; i += stride) {
+        const float4 a = wh4[i];
+        km_one<KMAX>(a.x, a.y, cw, ch, k, sacc, scnt, inertia, changed, lab + 2 * i);
+        km_one<KMAX>(a.z, a.w, cw, ch, k, sacc, scnt, inertia, changed, lab + 2 * i + 1);
+    }
+    if ((n & 1) && blockIdx.x == 0 && tid == 0) {
+        const float2 a = wh[n - 1];
+        km_one<KMAX>(a.x, a.y, cw, ch, k, sacc, scnt, inertia, changed, lab + (n - 1));
     }
 
     // block reduction: wave shuffles, then LDS across the 4 waves
-    __shared__ long long red[KM_BLOCK / 64][3 * KMAX + 2];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int c = 0; c < KMAX; ++c) {
-        long long a = wave_sum_ll(sw[c]), b2 = wave_sum_ll(sh[c]), c2 = wave_sum_ll((long long)cnt[c]);
+        long long a = wave_sum_ll((long long)sacc[(c * 2 + 0) * KM_BLOCK]), b2 = wave_sum_ll((long long)sacc[(c * 2 + 1) * KM_BLOCK]);
+        long long c2 = wave_sum_ll((long long)scnt[c * KM_BLOCK]);
         if (lane == 0) { red[wave][c] = a; red[wave][KMAX + c] = b2; red[wave][2 * KMAX + c] = c2; }
     }
     {
@@ -81,11 +116,11 @@ __global__ __launch_bounds__(KM_BLOCK) void k_kmeans_step(const float2 *__restri
         if (lane == 0) { red[wave][3 * KMAX] = a; red[wave][3 * KMAX + 1] = b2; }
     }
     __syncthreads();
-    if (threadIdx.x < 3 * KMAX + 2) {
+    if (tid < 3 * KMAX + 2) {
         long long v = 0;
 #pragma unroll
-        for (int w = 0; w < KM_BLOCK / 64; ++w) v += red[w][threadIdx.x];
-        partials[(int64_t)blockIdx.x * (3 * KMAX + 2) + threadIdx.x] = v;
+        for (int w = 0; w < KM_BLOCK / 64; ++w) v += red[w][tid];
+        partials[(int64_t)blockIdx.x * (3 * KMAX + 2) + tid] = v;
     }
 }
 
