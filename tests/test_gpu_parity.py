@@ -88,6 +88,47 @@ def test_nms_large_vs_oracle(va, oracle, n, dense, thr):
     assert np.array_equal(keep.cpu().numpy(), oracle.nms(b, s, thr)), (n, dense, thr)
 
 
+def test_nms_threshold_edges_vs_oracle(va, oracle):
+    """The mask phase tests inter/den < thr without dividing: thresholds that are exactly an IoU value of the set,
+    its float neighbours, 0, negatives, inf and NaN must all give the oracle's (dividing) answer."""
+    from vision_amd import ops
+    rng = np.random.default_rng(11)
+    for n in (700, 4500):                                  # one-wave reduce and the summary-driven reduce
+        xy = rng.integers(0, 40, (n, 2)).astype(np.float32)
+        wh = rng.integers(1, 9, (n, 2)).astype(np.float32)
+        b = np.concatenate([xy, xy + wh], 1)
+        s = wl.tiefree_scores(3, n)
+        vals = np.unique(oracle.iou_pairwise(b[:64], b[:256]))
+        vals = vals[(vals > 0) & (vals < 1)]
+        pick = vals[rng.choice(len(vals), 6, replace=False)]
+        thrs = []
+        for v in pick:
+            thrs += [v, np.nextafter(v, np.float32(2)), np.nextafter(v, np.float32(-1))]
+        thrs += [np.float32(0), np.float32(-0.25), np.float32(1), np.float32(np.inf), np.float32(np.nan), np.float32(1e-45)]
+        bt, st = torch.from_numpy(b)[None].cuda(), torch.from_numpy(s)[None].cuda()
+        for thr in thrs:
+            for quirk in (True, False):
+                keep, cnt = ops.nms_batched(bt, st, None, float(thr), quirk)
+                got = keep[0, :int(cnt[0])].cpu().numpy()
+                assert np.array_equal(got, oracle.nms(b, s, float(thr), quirk)), (n, thr, quirk)
+
+
+def test_nms_nonfinite_boxes_vs_oracle(va, oracle):
+    from vision_amd import ops
+    n = 4500
+    b, s = wl.stress_boxes(21, n, dense=True)
+    rng = np.random.default_rng(4)
+    idx = rng.choice(n, 40, replace=False)
+    b[idx[:10], 2] = np.inf
+    b[idx[10:20], 0] = np.nan
+    b[idx[20:30]] = np.float32(3e38) * np.array([-1, -1, 1, 1], np.float32)
+    b[idx[30:40], 3] = -np.inf
+    with np.errstate(all="ignore"):
+        want = oracle.nms(b, s, 0.5, True)
+    keep, cnt = ops.nms_batched(torch.from_numpy(b)[None].cuda(), torch.from_numpy(s)[None].cuda(), None, 0.5, True)
+    assert np.array_equal(keep[0, :int(cnt[0])].cpu().numpy(), want)
+
+
 def test_nms_batched_ragged_vs_oracle(va, oracle):
     from vision_amd import ops
     B, N = 9, 300

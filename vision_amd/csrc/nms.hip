@@ -12,15 +12,17 @@
 //            OR-ed into per-thread `removed` words.  Implements the reference's `numel()>1`
 //            quirk exactly.
 #include "common.hpp"
+#include <string.h>
+#include <math.h>
 
 #define SORT_CHUNK 4096  // elements sorted inside LDS (32 KiB of keys)
 
 struct NmsWs {
-    int64_t Np, W, Np2;
+    int64_t Np, W, SW, Np2;
     u64 *keys;
     float *x1, *y1, *x2, *y2, *area;
     int32_t *order;
-    u64 *mask;
+    u64 *mask, *rsum;
     size_t total;
 };
 
@@ -31,6 +33,7 @@ static NmsWs nms_layout(int64_t batch, int64_t nmax, void *base)
     NmsWs w;
     w.Np = dg_round_up(nmax > 0 ? nmax : 1, 64);
     w.W = w.Np / 64;
+    w.SW = dg_cdiv(w.W, 64);
     w.Np2 = next_pow2(nmax);
     char *p = (char *)base;
     size_t off = 0;
@@ -43,6 +46,7 @@ static NmsWs nms_layout(int64_t batch, int64_t nmax, void *base)
     w.area = (float *)take((size_t)batch * w.Np * 4);
     w.order = (int32_t *)take((size_t)batch * w.Np * 4);
     w.mask = (u64 *)take((size_t)batch * w.Np * w.W * 8);
+    w.rsum = (u64 *)take((size_t)batch * w.Np * w.SW * 8);
     w.total = off;
     return w;
 }
@@ -156,55 +160,121 @@ __global__ __launch_bounds__(256) void k_nms_gather(const float4 *__restrict__ b
 }
 
 // ---------------------------------------------------------------- mask
-// grid: x = column tile (16 words = 1024 columns), y = 64-row block, z = image.  256 threads.
-#define MASK_WORDS 16
-__global__ __launch_bounds__(256) void k_nms_mask(const float *__restrict__ sx1, const float *__restrict__ sy1,
+// grid: x = column tile (64 words = 4096 columns), y = 64-row block, z = image.  256 threads; a wave
+// owns 16 of the tile's 64 word-columns.  One lane owns one column; the row box is an LDS broadcast.
+//
+// The test !(inter/den < thr) is done without the division.  With p = the float below thr and
+// m = (p+thr)/2, a correctly rounded quotient is < thr exactly when the real quotient is below m
+// (or equal to m when the tie rounds down to p, i.e. thr's mantissa is odd).
+//   fast path (2^-20 <= thr < inf, all areas finite): e1 = fma(-thr,den,inter) and e2 = fma(-p,den,inter)
+//   carry the exact signs of inter-thr*den and inter-p*den (single rounding, no underflow in this
+//   range).  e1 >= 0 -> suppressed; e2 <= 0 -> kept; only p < q < thr (one ulp wide) needs more, and
+//   a wave that sees such a lane redoes that row exactly;
+//   exact path: m has 25 significant bits and den 24, so m*den is exact in double and so is the compare.
+//   NaNs fall to "suppress" through the negated compare, like the division did.
+//
+// Besides the mask words, every row gets a summary: bit w of rsum[row][t] says word 64t+w is non-zero.
+// The reduce phase walks summaries, so it touches only the non-zero words of the rows it keeps.
+#define MT_WORDS 64
+template <bool TIE_EVEN>
+__device__ __forceinline__ bool nms_suppressed(float inter, float den, double mid)
+{
+    const double prod = mid * (double)den, di = (double)inter;
+    return TIE_EVEN ? !(di < prod) : !(di <= prod);
+}
+
+// v_min/v_max as such: fminf/fmaxf would first canonicalise every operand (one more VALU op each); with
+// quiet NaNs the result is the same, the non-NaN operand
+__device__ __forceinline__ float vmin(float a, float b) { float o; asm("v_min_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b)); return o; }
+__device__ __forceinline__ float vmax(float a, float b) { float o; asm("v_max_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b)); return o; }
+
+template <bool TIE_EVEN>
+__global__ __launch_bounds__(256, 2) void k_nms_mask(const float *__restrict__ sx1, const float *__restrict__ sy1,
                                                   const float *__restrict__ sx2, const float *__restrict__ sy2,
                                                   const float *__restrict__ sarea, const int32_t *__restrict__ counts,
-                                                  int64_t nmax, int64_t Np, int64_t W, float thr, u64 *__restrict__ mask)
+                                                  int64_t nmax, int64_t Np, int64_t W, int64_t SW, float thr, float thr_below,
+                                                  double mid, int fast_ok, u64 *__restrict__ mask, u64 *__restrict__ rsum)
 {
     __shared__ float4 rbox[64];
     __shared__ float rarea[64];
-    __shared__ u64 tile[64][MASK_WORDS + 1];
+    __shared__ u64 tile[64][MT_WORDS + 1];
     const int img = blockIdx.z;
     const int n = counts ? counts[img] : (int)nmax;
     const int ib = blockIdx.y;
-    const int jb0 = blockIdx.x * MASK_WORDS;
-    if (ib * 64 >= n || jb0 * 64 >= n || jb0 + MASK_WORDS <= ib) return;   // below the diagonal / outside
+    const int jt = blockIdx.x, jb0 = jt * MT_WORDS;
+    if (ib * 64 >= n || (int64_t)jb0 * 64 >= n || jb0 + MT_WORDS <= ib) return;   // below the diagonal / outside
     const int64_t o = (int64_t)img * Np;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 64) {
-        int64_t i = o + ib * 64 + tid;
+        const int64_t i = o + ib * 64 + tid;
         rbox[tid] = make_float4(sx1[i], sy1[i], sx2[i], sy2[i]);
         rarea[tid] = sarea[i];
     }
     __syncthreads();
+    const bool rowbad = __ballot(!(rarea[lane] < INFINITY)) != 0ull;
 #pragma unroll 1
-    for (int q = 0; q < MASK_WORDS / 4; ++q) {
+    for (int q = 0; q < MT_WORDS / 4; ++q) {
         const int wi = wave + 4 * q;
         const int jb = jb0 + wi;
-        u64 myword = 0;
-        if (jb >= ib && jb < W && jb * 64 < n) {          // wave-uniform
+        asm volatile("" ::: "memory");                             // keep the row reads inside the loop, not in 320 registers
+        if (jb >= ib && jb < W && (int64_t)jb * 64 < n) {          // wave-uniform
             const int64_t j = o + (int64_t)jb * 64 + lane;
             const float cx1 = sx1[j], cy1 = sy1[j], cx2 = sx2[j], cy2 = sy2[j], ca = sarea[j];
-#pragma unroll 8
-            for (int r = 0; r < 64; ++r) {
-                float4 p = rbox[r];
-                float iou = dg_iou(p.x, p.y, p.z, p.w, rarea[r], cx1, cy1, cx2, cy2, ca, 1e-7f);
-                u64 bal = __ballot(!(iou < thr));         // yolo.py:201 keeps iou < thr; NaN is suppressed
-                if (lane == r) myword = bal;
+            const bool colbad = __ballot(!(ca < INFINITY)) != 0ull;
+            bool exact = !(fast_ok && !rowbad && !colbad);
+            if (!exact) {
+                u32 wlo = 0, whi = 0;
+                u64 ambany = 0;
+#pragma unroll
+                for (int r = 0; r < 64; ++r) {
+                    const float4 p = rbox[r];
+                    const float ix = vmax(vmin(p.z, cx2) - vmax(p.x, cx1), 0.0f);
+                    const float iy = vmax(vmin(p.w, cy2) - vmax(p.y, cy1), 0.0f);
+                    const float inter = ix * iy;
+                    const float den = ((rarea[r] + ca) - inter) + 1e-7f;
+                    const float e1 = __builtin_fmaf(-thr, den, inter), e2 = __builtin_fmaf(-thr_below, den, inter);
+                    const u64 bal = __ballot(!(e1 < 0.0f));
+                    ambany |= __ballot(e2 > 0.0f) & ~bal;               // p < q < thr somewhere in this row
+                    asm("v_writelane_b32 %0, %1, %2" : "+v"(wlo) : "s"((u32)bal), "n"(r));
+                    asm("v_writelane_b32 %0, %1, %2" : "+v"(whi) : "s"((u32)(bal >> 32)), "n"(r));
+                }
+                u64 myword = ((u64)whi << 32) | wlo;
+                if (jb == ib) myword &= ~((2ull << lane) - 1ull);   // only j > i
+                tile[lane][wi] = myword;
+                exact = ambany != 0ull;                              // rare: redo this word with the exact test
             }
-            if (jb == ib) myword &= ~((2ull << lane) - 1ull);   // only j > i
+            if (exact) {
+#pragma unroll 2
+                for (int r = 0; r < 64; ++r) {
+                    const float4 p = rbox[r];
+                    const float ix = fmaxf(fminf(p.z, cx2) - fmaxf(p.x, cx1), 0.0f);
+                    const float iy = fmaxf(fminf(p.w, cy2) - fmaxf(p.y, cy1), 0.0f);
+                    const float inter = ix * iy;
+                    const float den = ((rarea[r] + ca) - inter) + 1e-7f;
+                    u64 bal = __ballot(nms_suppressed<TIE_EVEN>(inter, den, mid));   // yolo.py:201 keeps iou < thr
+                    if (jb == ib) bal &= ~((2ull << r) - 1ull);
+                    if (lane == 0) tile[r][wi] = bal;
+                }
+            }
+        } else {
+            tile[lane][wi] = 0ull;
         }
-        tile[lane][wi] = myword;
     }
     __syncthreads();
-    // 64 rows x 16 words out, 128 contiguous bytes per row
+    if (tid < 64) {
+        u64 sbits = 0;
+#pragma unroll 8
+        for (int w = 0; w < MT_WORDS; ++w) sbits |= (u64)(tile[tid][w] != 0ull) << w;
+        rsum[(o + (int64_t)ib * 64 + tid) * SW + jt] = sbits;
+    }
+    // 64 rows x 64 words out, 512 contiguous bytes per row
     u64 *mo = mask + (o + (int64_t)ib * 64) * W + jb0;
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        int row = (tid >> 4) + 16 * p, word = tid & 15;
-        if (jb0 + word < W) mo[(int64_t)row * W + word] = tile[row][word];
+    if (jb0 + lane < W) {
+#pragma unroll 4
+        for (int p = 0; p < 16; ++p) {
+            const int row = wave + 4 * p;
+            mo[(int64_t)row * W + lane] = tile[row][lane];
+        }
     }
 }
 
@@ -313,6 +383,148 @@ __global__ __launch_bounds__(T) void k_nms_reduce(const u64 *__restrict__ mask, 
     if (tid == 0) keep_count[img] = total;
 }
 
+// Reduce for long segments (W > 64): `removed` lives in LDS and only the non-zero words of kept rows are
+// fetched, found through the row summaries.  Every wave resolves the diagonal word itself (rows whose
+// diagonal word is zero cannot suppress anything, so the serial chain only visits the others), then
+// the kept rows are dealt round-robin to the waves and OR-ed in with LDS atomics: one barrier per block.
+// removed1 lags removed2 by the most recent block's last kept row, so at the end it holds the state
+// "before the last kept box was applied" that the numel()>1 quirk asks about.
+template <int T>
+__global__ __launch_bounds__(T) void k_nms_reduce_sum(const u64 *__restrict__ mask, const u64 *__restrict__ rsum,
+                                                      const int32_t *__restrict__ order, const int32_t *__restrict__ counts,
+                                                      int64_t nmax, int64_t Np, int64_t W, int64_t SW, int quirk,
+                                                      int64_t *__restrict__ keep, int32_t *__restrict__ keep_count)
+{
+    static_assert(T == 1024, "thread <-> (row, summary word) mapping assumes 1024 threads");
+    extern __shared__ u64 nms_lds[];
+    __shared__ u64 sumring[2][64][16];
+    u64 *remv2 = nms_lds, *remv1 = nms_lds + W;
+    constexpr int NW = T / 64, RPW = 64 / NW;
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = counts ? counts[img] : (int)nmax;
+    mask += (int64_t)img * Np * W;
+    rsum += (int64_t)img * Np * SW;
+    order += (int64_t)img * Np;
+    keep += (int64_t)img * nmax;
+    for (int w = tid; w < (int)W; w += T) {
+        const int64_t base = (int64_t)w * 64;
+        const u64 v = (base >= n) ? ~0ull : ((n - base >= 64) ? 0ull : (~0ull << (n - base)));
+        remv2[w] = v; remv1[w] = v;
+    }
+    __syncthreads();
+    const int nb = (n + 63) >> 6, SWn = (nb + 63) >> 6;
+    int total = 0, last_ib = -1, last_r = 0;
+    u64 last_curb = 0;
+    const int quarter = lane & 3, sl = lane >> 2;
+    // summaries of the next block's 64 rows are fetched one block ahead into an LDS ring (they do not
+    // depend on what is kept); W <= 1024 here, so a row has at most 16 summary words
+    auto sum_fetch = [&](int b) -> u64 {
+        const int s = (b >> 6) + (tid & 15);
+        return (b < nb && s < SWn) ? rsum[((int64_t)b * 64 + (tid >> 4)) * SW + s] : 0ull;
+    };
+    sumring[0][tid >> 4][tid & 15] = sum_fetch(0);
+    __syncthreads();
+    u32 pbits = 0;          // the pending row's 16-word piece seen by this lane, and where it starts
+    int pwbase = 0;
+
+    u64 diag_next = (nb > 0) ? mask[(int64_t)lane * W] : 0ull;
+    int ahead = 0;                                          // block whose diagonal word and summaries were fetched ahead
+    for (int ib = 0; ib < nb; ++ib) {
+        u64 cur = uniform64(remv2[ib]);
+        if (cur == ~0ull) continue;                         // block already suppressed (uniform; nothing writes words <= ib now)
+        if (ahead != ib) {                                  // came here over skipped blocks: fetch now
+            diag_next = mask[((int64_t)ib * 64 + lane) * W + ib];
+            sumring[ib & 1][tid >> 4][tid & 15] = sum_fetch(ib);
+            __syncthreads();
+        }
+        const u64 diag = diag_next;
+        if (ib + 1 < nb) diag_next = mask[((int64_t)(ib + 1) * 64 + lane) * W + ib + 1];
+        const u64 sum_next = sum_fetch(ib + 1);
+        ahead = ib + 1;
+        u64 curb = cur;
+        int lastact = -1;
+        {
+            u64 m = uniform64(__ballot(diag != 0ull));
+            while (m) {
+                const int r = __builtin_ctzll(m);
+                m &= m - 1;
+                if (!((cur >> r) & 1ull)) { curb = cur; lastact = r; cur |= readlane64(diag, r); }
+            }
+        }
+        const u64 kept = ~cur;
+        const int nk = __builtin_popcountll(kept);
+        if (nk) {                                            // uniform
+            const int rl = 63 - __builtin_clzll(kept);
+            const bool mine = (kept >> lane) & 1ull;
+            const int rank = __builtin_popcountll(kept & ((1ull << lane) - 1ull));
+            if (wave == 0 && mine) keep[total + rank] = (int64_t)order[ib * 64 + lane];
+            // this wave's rows: the kept rows number wave, wave+NW, ...; the previous kept block's last row
+            // (for removed1 only) goes to wave nk % NW
+            int rr[RPW];
+#pragma unroll
+            for (int j = 0; j < RPW; ++j) {
+                const u64 b = __ballot(mine && rank == wave + NW * j);
+                rr[j] = b ? __builtin_ctzll(b) : -1;
+            }
+            const bool pend = last_ib >= 0 && (nk % NW) == wave;
+            const int64_t prow = (int64_t)last_ib * 64 + last_r;
+            const int s = (ib >> 6) + sl;
+            const int wbase = s * 64 + 16 * quarter;
+            auto live_from = [&](int base) -> u32 {          // words <= ib are of no further use
+                const int lo = ib - base;
+                return lo < 0 ? 0xffffu : (lo >= 15 ? 0u : ((0xffffu << (lo + 1)) & 0xffffu));
+            };
+            const u32 live = (s < SWn) ? live_from(wbase) : 0u;
+            u32 bits[RPW], bp = pend ? (pbits & live_from(pwbase)) : 0u;
+#pragma unroll
+            for (int j = 0; j < RPW; ++j)
+                bits[j] = (rr[j] >= 0) ? ((u32)(sumring[ib & 1][rr[j]][sl] >> (16 * quarter)) & live) : 0u;
+            for (;;) {
+                u32 any = bp;
+#pragma unroll
+                for (int j = 0; j < RPW; ++j) any |= bits[j];
+                if (!any) break;
+                u64 v[RPW], vp = 0;
+                int wj[RPW], wp = 0;
+#pragma unroll
+                for (int j = 0; j < RPW; ++j) {
+                    v[j] = 0; wj[j] = 0;
+                    if (bits[j]) {
+                        wj[j] = wbase + __builtin_ctz(bits[j]);
+                        bits[j] &= bits[j] - 1;
+                        v[j] = mask[((int64_t)ib * 64 + rr[j]) * W + wj[j]];
+                    }
+                }
+                if (bp) { wp = pwbase + __builtin_ctz(bp); bp &= bp - 1; vp = mask[prow * W + wp]; }
+#pragma unroll
+                for (int j = 0; j < RPW; ++j) {
+                    if (v[j]) {
+                        atomicOr((unsigned long long *)&remv2[wj[j]], (unsigned long long)v[j]);
+                        if (rr[j] != rl) atomicOr((unsigned long long *)&remv1[wj[j]], (unsigned long long)v[j]);
+                    }
+                }
+                if (vp) atomicOr((unsigned long long *)&remv1[wp], (unsigned long long)vp);
+            }
+            pbits = (s < SWn) ? ((u32)(sumring[ib & 1][rl][sl] >> (16 * quarter)) & 0xffffu) : 0u;
+            pwbase = wbase;
+            last_ib = ib; last_r = rl; last_curb = (rl == lastact) ? curb : cur;
+            total += nk;
+        }
+        sumring[(ib + 1) & 1][tid >> 4][tid & 15] = sum_next;
+        __syncthreads();
+    }
+    if (quirk && total > 0) {
+        // yolo.py:196 `while ids_sorted.numel()>1`: the last kept box is dropped iff nothing ranked below it
+        // was still alive before its own row was applied.
+        const u64 above = (last_r == 63) ? 0ull : (~0ull << (last_r + 1));
+        int surv = (tid == 0) ? (((~last_curb) & above) != 0ull) : 0;
+        for (int w = last_ib + 1 + tid; w < (int)W; w += T) surv |= (~remv1[w]) != 0ull;
+        surv = __syncthreads_or(surv);
+        if (!surv) total -= 1;
+    }
+    if (tid == 0) keep_count[img] = total;
+}
+
 // ---------------------------------------------------------------- host
 extern "C" size_t dg_nms_workspace_bytes(int64_t batch, int64_t nmax)
 {
@@ -382,9 +594,21 @@ extern "C" int dg_nms_phase_mask(const int32_t *counts, int64_t batch, int64_t n
     NmsWs w;
     int rc = nms_check("nms_mask", batch, nmax, ws, ws_bytes, &w);
     if (rc || batch == 0 || nmax == 0) return rc;
-    dim3 grid((unsigned)dg_cdiv(w.W, MASK_WORDS), (unsigned)w.W, (unsigned)batch);
-    hipLaunchKernelGGL(k_nms_mask, grid, dim3(256), 0, (hipStream_t)s, w.x1, w.y1, w.x2, w.y2, w.area, counts, nmax, w.Np, w.W,
-                       threshold, w.mask);
+    // midpoint between thr and the float below it, and which way a quotient exactly on it rounds (see k_nms_mask)
+    double mid;
+    if (threshold != threshold) mid = (double)threshold;
+    else mid = ((double)nextafterf(threshold, -INFINITY) + (double)threshold) * 0.5;
+    uint32_t tbits;
+    memcpy(&tbits, &threshold, 4);
+    const int fast_ok = threshold >= 0x1p-20f && threshold < INFINITY;
+    const float below = fast_ok ? nextafterf(threshold, -INFINITY) : threshold;
+    dim3 grid((unsigned)dg_cdiv(w.W, MT_WORDS), (unsigned)w.W, (unsigned)batch);
+    if ((tbits & 1u) == 0)
+        hipLaunchKernelGGL(k_nms_mask<true>, grid, dim3(256), 0, (hipStream_t)s, w.x1, w.y1, w.x2, w.y2, w.area, counts, nmax, w.Np,
+                           w.W, w.SW, threshold, below, mid, fast_ok, w.mask, w.rsum);
+    else
+        hipLaunchKernelGGL(k_nms_mask<false>, grid, dim3(256), 0, (hipStream_t)s, w.x1, w.y1, w.x2, w.y2, w.area, counts, nmax, w.Np,
+                           w.W, w.SW, threshold, below, mid, fast_ok, w.mask, w.rsum);
     DG_CHECK_LAUNCH("k_nms_mask");
     return DG_OK;
 }
@@ -402,7 +626,9 @@ extern "C" int dg_nms_phase_reduce(const int32_t *counts, int64_t batch, int64_t
 #define RED(T, WPT) hipLaunchKernelGGL((k_nms_reduce<T, WPT>), dim3((unsigned)batch), dim3(T), 0, st, w.mask, w.order, counts, \
                                        nmax, w.Np, w.W, quirk_drop_last, keep, keep_count)
     if (w.W <= 64) RED(64, 1);
-    else if (w.W <= 1024) RED(1024, 1);
+    else if (w.W <= 1024)
+        hipLaunchKernelGGL((k_nms_reduce_sum<1024>), dim3((unsigned)batch), dim3(1024), (size_t)w.W * 16, st, w.mask, w.rsum, w.order,
+                           counts, nmax, w.Np, w.W, w.SW, quirk_drop_last, keep, keep_count);
     else if (w.W <= 4096) RED(1024, 4);
     else RED(1024, 16);
 #undef RED
