@@ -77,7 +77,9 @@ __global__ __launch_bounds__(256) void k_iou_pairwise_f32(const float4 *__restri
             v.y = dg_iou(p.x, p.y, p.z, p.w, pa, c[1].x, c[1].y, c[1].z, c[1].w, ca[1], eps);
             v.z = dg_iou(p.x, p.y, p.z, p.w, pa, c[2].x, c[2].y, c[2].z, c[2].w, ca[2], eps);
             v.w = dg_iou(p.x, p.y, p.z, p.w, pa, c[3].x, c[3].y, c[3].z, c[3].w, ca[3], eps);
-            *reinterpret_cast<float4 *>(o) = v;
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const v4f t = {v.x, v.y, v.z, v.w};
+            __builtin_nontemporal_store(t, reinterpret_cast<v4f *>(o));          // written once, streamed
             o += m;
         }
     } else {
