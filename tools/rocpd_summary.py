@@ -3,6 +3,7 @@ usage: python tools/rocpd_summary.py stats <db> > kernel_stats.csv      # per (k
        python tools/rocpd_summary.py pmc <db> [kernel-substring]         # per (kernel, grid, counter) means
 Launches of one kernel at different grid sizes are kept apart so that the bench's full-size launches
 are not averaged with the small side configurations that run in the same process."""
+import math
 import sqlite3
 import sys
 
@@ -15,14 +16,15 @@ def main():
     mode, db = sys.argv[1], sys.argv[2]
     con = sqlite3.connect(db)
     if mode == "stats":
-        cols = [r[1] for r in con.execute("pragma table_info(kernels)")]
-        gcol = "grid_size" if "grid_size" in cols else "grid_size_x"
-        rows = con.execute(f"select name, {gcol}, workgroup_size, count(*), sum(end-start), avg(end-start), min(end-start), max(end-start) "
-                           f"from kernels group by name, {gcol}, workgroup_size order by sum(end-start) desc").fetchall()
-        tot = sum(r[4] for r in rows) or 1
-        print("kernel,grid_threads,workgroup,calls,total_us,avg_us,min_us,max_us,percent")
-        for n, g, wg, c, s, a, mn, mx in rows:
-            print(f"\"{short(n)}\",{g},{wg},{c},{s/1e3:.1f},{a/1e3:.2f},{mn/1e3:.2f},{mx/1e3:.2f},{100*s/tot:.2f}")
+        # a persistent kernel has one grid for every problem size: launches are also split by decade of duration
+        groups = {}
+        for n, g, wg, st, en in con.execute("select name, grid_x*grid_y*grid_z, workgroup_x*workgroup_y*workgroup_z, start, end from kernels"):
+            d = (en - st) / 1e3
+            groups.setdefault((short(n), g, wg, int(math.floor(math.log10(max(d, 1e-3))))), []).append(d)
+        tot = sum(sum(v) for v in groups.values()) or 1
+        print("kernel,grid_threads,workgroup,duration_decade_us,calls,total_us,avg_us,min_us,max_us,percent")
+        for (n, g, wg, dec), v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
+            print(f"\"{n}\",{g},{wg},1e{dec},{len(v)},{sum(v):.1f},{sum(v)/len(v):.2f},{min(v):.2f},{max(v):.2f},{100*sum(v)/tot:.2f}")
     else:
         sub = sys.argv[3] if len(sys.argv) > 3 else ""
         rows = con.execute("select kernel_name, grid_size, counter_name, count(*), avg(value), avg(duration) from counters_collection "
