@@ -242,6 +242,38 @@ def test_roipool_config1_vs_oracle(va, oracle):
     np.testing.assert_allclose(gin, wgin, rtol=1e-4, atol=1e-4)     # fp32 sums of ~50 terms in a different order
 
 
+@pytest.mark.parametrize("with_nan", [False, True])
+def test_roipool_every_crop_width_with_ties(va, oracle, with_nan):
+    """Every crop width 1..50 (the width-specialised, the generic staged and the direct code paths) at assorted heights,
+    on a map quantised to a few levels so that almost every bin has tied maxima (first one must win, as in ATen),
+    with both signs of zero, and optionally NaNs (a NaN always wins)."""
+    from vision_amd import ops
+    rng = np.random.default_rng(17)
+    B, C, H, W = 2, 128, 38, 50
+    levels = np.array([-2.0, -1.0, -0.0, 0.0, 0.5, 1.0], np.float32)
+    img = levels[rng.integers(0, len(levels), (B, C, H, W))]
+    if with_nan:
+        img[rng.random(img.shape) < 0.002] = np.nan
+    wins = []
+    for lw in range(1, W + 1):
+        for lh in sorted(set(int(v) for v in rng.integers(1, H + 1, 5)) | {1 + lw % 7, H if lw % 9 == 0 else 7}):
+            x1 = int(rng.integers(0, W - lw + 1)); y1 = int(rng.integers(0, H - lh + 1))
+            wins.append((x1, y1, x1 + lw, y1 + lh))
+    wins = np.array(wins, np.int64)
+    rois = np.stack([(wins[:, 0] + 0.25) / W, (wins[:, 1] + 0.25) / H, (wins[:, 2] - 0.25) / W, (wins[:, 3] - 0.25) / H], 1)
+    idx = rng.integers(0, B, len(wins)).astype(np.int64)
+    x = torch.from_numpy(img).cuda()
+    win, status = ops.roi_windows(rois, idx, B, H, W, x.device)
+    assert int(status.item()) == 0 and np.array_equal(win.cpu().numpy()[:, :4], wins)
+    out, arg = ops.roipool_forward(x, win, "max")
+    want, warg = oracle.roipool_fwd(img, rois, idx, 7, "max")
+    got = out.cpu().numpy()
+    bad = (got.view(np.uint32) != want.view(np.uint32)) & ~np.isnan(want)                                  # bits: -0 stays -0
+    assert not bad.any(), sorted(set((wins[:, 2] - wins[:, 0])[bad.reshape(len(wins), -1).any(1)]))
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    assert np.array_equal(arg.cpu().numpy(), warg)
+
+
 def test_roipool_odd_channels_and_batch(va, oracle):
     from vision_amd import ops
     rng = np.random.default_rng(2)

@@ -71,7 +71,7 @@ template <bool NANSAFE>
 __device__ __forceinline__ void max_upd(float &best, int &bi, float v, int idx)
 {
     if (NANSAFE) { if ((v > best) || (v != v)) { best = v; bi = idx; } }
-    else         { bi = (v > best) ? idx : bi; best = fmaxf(best, v); }   // v_max_f32 is full rate, v_cmp/v_cndmask half rate
+    else         { const bool g = v > best; bi = g ? idx : bi; best = g ? v : best; }   // strict: -0 is not replaced by a later +0
 }
 
 // The pooled output is written once and not read again by this kernel: non-temporal 16-byte stores keep it
@@ -88,6 +88,10 @@ __device__ __forceinline__ void nt_store4(int32_t *p, int4 v)
     dg_v4i t = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(t, reinterpret_cast<dg_v4i *>(p));
 }
+
+// v_max_f32 / v_max3_f32 as such: fmaxf would first canonicalise operands that come straight from memory
+__device__ __forceinline__ float vmaxf(float a, float b) { float o; asm("v_max_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b)); return o; }
+__device__ __forceinline__ float vmax3f(float a, float b, float c) { float o; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c)); return o; }
 
 #ifdef DG_STAMPS
 // diagnostic build only (tools/ubench/roi_fwd_stamps.hip): where a task spends its cycles
@@ -200,8 +204,113 @@ __device__ __forceinline__ void roi_task_staged(char *smem, const char *__restri
     }
 }
 
+// Staged task for NaN-free maps, specialised on the crop width LW (1..24): the adaptive column bins are
+// compile-time constants, so every LDS read is `row base + immediate`, no position is read twice for one bin
+// and no per-lane address table exists.  Per (row, bin): the row's maximum over the bin's pixels (v_max3),
+// then one strict compare against the running maximum, which records the row -- the first row holding the
+// maximum wins, as in ATen.  The column is recovered once per bin at the end of the strip: the first pixel of
+// the winning row that equals the maximum (the row is still in the ring: the prefetch issued at the start of
+// the strip only overwrote rows above it).  The value written is that pixel's own bits (-0 stays -0).
+template <int LW>
+__device__ __forceinline__ void roi_task_exact(char *smem, const char *__restrict__ imgc0, int pixbytes, int W, int lane,
+                                               int x1, int y1, int y2, int R, float (&oval)[RBINS], int (&oidx)[RBINS]
+#ifdef DG_STAMPS
+                                               , unsigned long long *stamp_loc
+#endif
+                                               )
+{
+    constexpr int Lwp = (LW + 3) & ~3, NQ = Lwp >> 2, rowbytes = Lwp * 256;
+    const int Lh = y2 - y1;
+    const int pxl = lane >> 4;
+    unsigned voff[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) voff[q] = (unsigned)(min(4 * q + pxl, LW - 1) * pixbytes + (lane & 15) * 16);
+    int loaded = y1, lslot = 0;
+    auto issue_rows = [&](int ylimit) {
+        while (loaded < ylimit) {
+            const char *rowg = imgc0 + (int64_t)(loaded * W + x1) * pixbytes;      // uniform
+            char *rowl = smem + lslot * rowbytes;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rowg + voff[q]),
+                                                 (__attribute__((address_space(3))) void *)(rowl + q * 1024), 16, 0, 0);
+            lslot = (lslot + 1 == R) ? 0 : lslot + 1;
+            ++loaded;
+        }
+    };
+    STAMP(tp0);
+    issue_rows(min(y2, y1 + R));
+    STAMP(tp1);
+    STAMP_ADD(0, tp0, tp1);
+    const char *lbase = smem + lane * 4;
+    int slot = 0, prev_hs = y1;
+#pragma unroll
+    for (int ph = 0; ph < RP; ++ph) {
+        const int hs = y1 + (ph * Lh) / RP, he = y1 + ((ph + 1) * Lh + RP - 1) / RP;
+        STAMP(t0);
+        issue_rows(he);                                    // normally already issued
+        STAMP(t1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // rows < he have landed
+        STAMP(t2);
+        issue_rows(min(y2, hs + R));                       // prefetch; only overwrites rows < hs
+        STAMP(t3);
+        STAMP_ADD(0, t0, t1); STAMP_ADD(1, t1, t2); STAMP_ADD(0, t2, t3);
+        slot += hs - prev_hs;                              // hs advances by <= maxrows <= R
+        if (slot >= R) slot -= R;
+        prev_hs = hs;
+        float best[RP];
+        int brow[RP];
+#pragma unroll
+        for (int i = 0; i < RP; ++i) { best[i] = -INFINITY; brow[i] = 0; }
+        int sl = slot, so = slot * rowbytes;
+        for (int r = 0; r < he - hs; ++r) {
+            const char *rowp = lbase + so;
+#pragma unroll
+            for (int i = 0; i < RP; ++i) {
+                constexpr int dummy = 0; (void)dummy;
+                const int s = (i * LW) / RP, w = ((i + 1) * LW + RP - 1) / RP - s;      // folded: i and LW are constants
+                float rm = *(const float *)(rowp + s * 256);
+                int j = 1;
+#pragma unroll
+                for (; j + 1 < w; j += 2)
+                    rm = vmax3f(rm, *(const float *)(rowp + (s + j) * 256), *(const float *)(rowp + (s + j + 1) * 256));
+                if (j < w) rm = vmaxf(rm, *(const float *)(rowp + (s + j) * 256));
+                brow[i] = (rm > best[i]) ? r : brow[i];
+                best[i] = vmaxf(best[i], rm);
+            }
+            so += rowbytes;
+            if (++sl == R) { sl = 0; so = 0; }
+        }
+        STAMP(t4);
+        const int ibase = hs * W + x1;
+#pragma unroll
+        for (int i = 0; i < RP; ++i) {
+            const int s = (i * LW) / RP, w = ((i + 1) * LW + RP - 1) / RP - s;
+            int rs = slot + brow[i];                       // ring slot of the winning row (per lane)
+            rs = (rs >= R) ? rs - R : rs;
+            const char *rowp = lbase + rs * rowbytes;
+            int c = 0;
+            float bv = best[i];
+#pragma unroll
+            for (int j = w - 1; j >= 0; --j) {
+                const float a = *(const float *)(rowp + (s + j) * 256);
+                const bool hit = (a == best[i]);
+                c = hit ? j : c;
+                bv = hit ? a : bv;
+            }
+            oval[ph * RP + i] = bv;
+            oidx[ph * RP + i] = ibase + brow[i] * W + s + c;
+        }
+        // The reads above must have returned before the next strip issues LDS-DMA into the rows they came from:
+        // issue order alone does not keep a DMA write behind a ds_read that is still queued.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        STAMP(t5);
+        STAMP_ADD(2, t3, t4); STAMP_ADD(3, t4, t5);
+    }
+}
+
 template <int MODE>
-__global__ __launch_bounds__(64) void k_roipool_fwd(const float *__restrict__ nhwc, int C, int H, int W,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_roipool_fwd(const float *__restrict__ nhwc, int C, int H, int W,
                                                     const int32_t *__restrict__ win, int cblocks, int64_t ntasks,
                                                     const int32_t *__restrict__ nan_flag,
                                                     float *__restrict__ out, int32_t *__restrict__ argmax, int vec_ok)
@@ -209,7 +318,7 @@ __global__ __launch_bounds__(64) void k_roipool_fwd(const float *__restrict__ nh
     __shared__ __attribute__((aligned(16))) float smemf[FWD_LDS_FLOATS];
     float *sval = smemf;
     unsigned short *sidx = reinterpret_cast<unsigned short *>(smemf + 64 * RBINS);
-    const int lane = threadIdx.x;
+    const int lane0 = threadIdx.x;
     const bool may_nan = nan_flag ? (__builtin_amdgcn_readfirstlane(nan_flag[0]) != 0) : true;
 #ifdef DG_STAMPS
     unsigned long long stamp_loc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -219,6 +328,10 @@ __global__ __launch_bounds__(64) void k_roipool_fwd(const float *__restrict__ nh
     // multiple of 8, so a workgroup (and the XCD it sits on, blockIdx % 8) keeps one channel slice of the map.
 #pragma unroll 1
     for (int64_t task = blockIdx.x; task < ntasks; task += gridDim.x) {
+        // opaque per task: otherwise every lane-derived LDS/global address of the loop body (about 100 of them) is
+        // hoisted out of the task loop and held in registers for the kernel's lifetime
+        int lane = lane0;
+        asm volatile("" : "+v"(lane));
         const int cbk = (int)(task % cblocks);
         const int64_t roi = task / cblocks;
         const int c0 = cbk * 64;
@@ -230,90 +343,9 @@ __global__ __launch_bounds__(64) void k_roipool_fwd(const float *__restrict__ nh
         const int cvalid = (C - c0) < 64 ? (C - c0) : 64;
 
         STAMP(ta);
-        bool staged = false;
-        if (MODE == DG_POOL_MAX) {
-            const int Lwp = (Lw + 3) & ~3;
-            const int R = RING_PX / Lwp;
-            // widest / tallest adaptive bin of a length L = 7q + r: q (r == 0), q + 1 (r == 1), q + 2 (r >= 2)
-            const int qw = Lw / RP, rw = Lw - qw * RP, qh = Lh / RP, rh = Lh - qh * RP;
-            const int maxw = qw + (rw > 1 ? 2 : rw), maxrows = qh + (rh > 1 ? 2 : rh);
-            staged = (R >= maxrows) && (maxw <= 4) && (Lwp <= 24) && (cvalid == 64) && ((C & 3) == 0) &&
-                     ((((uintptr_t)nhwc) & 15) == 0) && ((int64_t)H * W * C * 4 < (1ll << 31));
-            if (staged) {
-                float oval[RBINS];
-                int oidx[RBINS];
-                char *smem = reinterpret_cast<char *>(smemf);
-#ifdef DG_STAMPS
-#define STAMP_ARG , stamp_loc
-#else
-#define STAMP_ARG
-#endif
-                const char *imgc0 = reinterpret_cast<const char *>(nhwc + ((int64_t)b * H * W) * C + c0);
-#define STAGED(XWV)                                                                                                         \
-    if (may_nan) roi_task_staged<XWV, true>(smem, imgc0, C * 4, W, lane, x1, y1, x2, y2, R, oval, oidx STAMP_ARG);          \
-    else roi_task_staged<XWV, false>(smem, imgc0, C * 4, W, lane, x1, y1, x2, y2, R, oval, oidx STAMP_ARG)
-#ifdef DG_ONEVARIANT
-                roi_task_staged<4, false>(smem, imgc0, C * 4, W, lane, x1, y1, x2, y2, R, oval, oidx STAMP_ARG);
-#else
-                switch (maxw) {
-                case 1: STAGED(1); break;
-                case 2: STAGED(2); break;
-                case 3: STAGED(3); break;
-                default: STAGED(4); break;
-                }
-#endif
-#undef STAGED
-                STAMP(tw0);
-                // all ring reads are done (results are in registers): the transpose buffer may overwrite the ring
-#pragma unroll
-                for (int i = 0; i < RBINS; ++i) {
-                    sval[lane * RBINS + i] = oval[i];
-                    sidx[lane * RBINS + i] = (unsigned short)oidx[i];
-                }
-                STAMP(tw1);
-                STAMP_ADD(7, tw0, tw1);
-            }
-        }
-        if (!staged) {
-            // ---- direct path (any crop size, partial channel blocks, avg mode): reads the map from L2/HBM per bin
-            const int c = c0 + (lane < cvalid ? lane : cvalid - 1);
-            const float *base = nhwc + (int64_t)b * H * W * C + c;
-#pragma unroll 1
-            for (int ph = 0; ph < RP; ++ph) {
-                const int hs = y1 + (ph * Lh) / RP, he = y1 + ((ph + 1) * Lh + RP - 1) / RP;
-#pragma unroll 1
-                for (int pw = 0; pw < RP; ++pw) {
-                    const int ws = x1 + (pw * Lw) / RP, we = x1 + ((pw + 1) * Lw + RP - 1) / RP;
-                    if (MODE == DG_POOL_MAX) {
-                        float best = -INFINITY;
-                        int bi = hs * W + ws;
-                        for (int y = hs; y < he; ++y) {
-                            const float *row = base + (int64_t)y * W * C;
-                            for (int x = ws; x < we; x += 4) {
-                                // 4 independent loads in flight; past the bin's end: clamped re-reads (idempotent)
-                                const int xb = min(x + 1, we - 1), xc = min(x + 2, we - 1), xd = min(x + 3, we - 1);
-                                const float va = row[(int64_t)x * C], vb = row[(int64_t)xb * C];
-                                const float vc = row[(int64_t)xc * C], vd = row[(int64_t)xd * C];
-                                max_upd<true>(best, bi, va, y * W + x);
-                                max_upd<true>(best, bi, vb, y * W + xb);
-                                max_upd<true>(best, bi, vc, y * W + xc);
-                                max_upd<true>(best, bi, vd, y * W + xd);
-                            }
-                        }
-                        sval[lane * RBINS + ph * RP + pw] = best;
-                        sidx[lane * RBINS + ph * RP + pw] = (unsigned short)bi;
-                    } else {
-                        float sum = 0.f;
-                        for (int y = hs; y < he; ++y) {
-                            const float *row = base + (int64_t)y * W * C;
-                            for (int x = ws; x < we; ++x) sum += row[(int64_t)x * C];
-                        }
-                        sval[lane * RBINS + ph * RP + pw] = sum / (float)(he - hs) / (float)(we - ws);
-                    }
-                }
-            }
-        }
-        STAMP(tb);
+        // output phase; instantiated at the end of each path (staged / direct) so that the two paths do not merge
+        // with 98 result registers apparently live (the allocator then carries them around the whole task loop)
+        auto emit = [&]() {
         __syncthreads();
         // contiguous run of cvalid*49 outputs for this (roi, channel block)
         const int64_t obase = (roi * C + c0) * RBINS;
@@ -364,13 +396,108 @@ __global__ __launch_bounds__(64) void k_roipool_fwd(const float *__restrict__ nh
             }
         }
         __syncthreads();      // the buffer is reused by the next task's ring
+        };
+        bool staged = false;
+        if (MODE == DG_POOL_MAX) {
+            const int Lwp = (Lw + 3) & ~3;
+            const int R = RING_PX / Lwp;
+            // widest / tallest adaptive bin of a length L = 7q + r: q (r == 0), q + 1 (r == 1), q + 2 (r >= 2)
+            const int qw = Lw / RP, rw = Lw - qw * RP, qh = Lh / RP, rh = Lh - qh * RP;
+            const int maxw = qw + (rw > 1 ? 2 : rw), maxrows = qh + (rh > 1 ? 2 : rh);
+            staged = (R >= maxrows) && (Lwp <= 24) && (maxw <= 4 || (!may_nan && Lw <= 16)) && (cvalid == 64) && ((C & 3) == 0) &&
+                     ((((uintptr_t)nhwc) & 15) == 0) && ((int64_t)H * W * C * 4 < (1ll << 31));
+            if (staged) {
+                float oval[RBINS];
+                int oidx[RBINS];
+                char *smem = reinterpret_cast<char *>(smemf);
+#ifdef DG_STAMPS
+#define STAMP_ARG , stamp_loc
+#else
+#define STAMP_ARG
+#endif
+                const char *imgc0 = reinterpret_cast<const char *>(nhwc + ((int64_t)b * H * W) * C + c0);
+#define EXACT(LWV) case LWV: roi_task_exact<LWV>(smem, imgc0, C * 4, W, lane, x1, y1, y2, R, oval, oidx STAMP_ARG); break
+#define STAGED(XWV) roi_task_staged<XWV, true>(smem, imgc0, C * 4, W, lane, x1, y1, x2, y2, R, oval, oidx STAMP_ARG)
+                if (!may_nan) {
+                    switch (Lw) {
+                    EXACT(1); EXACT(2); EXACT(3); EXACT(4); EXACT(5); EXACT(6); EXACT(7); EXACT(8);
+                    EXACT(9); EXACT(10); EXACT(11); EXACT(12); EXACT(13); EXACT(14); EXACT(15); EXACT(16);
+                          
+                    default:                           // 17..24 wide: generic code, 3 or 4 positions per bin
+                        if (maxw <= 3) roi_task_staged<3, false>(smem, imgc0, C * 4, W, lane, x1, y1, x2, y2, R, oval, oidx STAMP_ARG);
+                        else roi_task_staged<4, false>(smem, imgc0, C * 4, W, lane, x1, y1, x2, y2, R, oval, oidx STAMP_ARG);
+                        break;
+                    }
+                } else {
+                    switch (maxw) {
+                    case 1: STAGED(1); break;
+                    case 2: STAGED(2); break;
+                    case 3: STAGED(3); break;
+                    default: STAGED(4); break;
+                    }
+                }
+#undef STAGED
+#undef EXACT
+                STAMP(tw0);
+                // all ring reads are done (results are in registers): the transpose buffer may overwrite the ring
+#pragma unroll
+                for (int i = 0; i < RBINS; ++i) {
+                    sval[lane * RBINS + i] = oval[i];
+                    sidx[lane * RBINS + i] = (unsigned short)oidx[i];
+                }
+                STAMP(tw1);
+                STAMP_ADD(7, tw0, tw1);
+                emit();
+            }
+        }
+        if (!staged) {
+            // ---- direct path (any crop size, partial channel blocks, avg mode): reads the map from L2/HBM per bin
+            const int c = c0 + (lane < cvalid ? lane : cvalid - 1);
+            const float *base = nhwc + (int64_t)b * H * W * C + c;
+#pragma unroll 1
+            for (int ph = 0; ph < RP; ++ph) {
+                const int hs = y1 + (ph * Lh) / RP, he = y1 + ((ph + 1) * Lh + RP - 1) / RP;
+#pragma unroll 1
+                for (int pw = 0; pw < RP; ++pw) {
+                    const int ws = x1 + (pw * Lw) / RP, we = x1 + ((pw + 1) * Lw + RP - 1) / RP;
+                    if (MODE == DG_POOL_MAX) {
+                        float best = -INFINITY;
+                        int bi = hs * W + ws;
+                        for (int y = hs; y < he; ++y) {
+                            const float *row = base + (int64_t)y * W * C;
+                            for (int x = ws; x < we; x += 4) {
+                                // 4 independent loads in flight; past the bin's end: clamped re-reads (idempotent)
+                                const int xb = min(x + 1, we - 1), xc = min(x + 2, we - 1), xd = min(x + 3, we - 1);
+                                const float va = row[(int64_t)x * C], vb = row[(int64_t)xb * C];
+                                const float vc = row[(int64_t)xc * C], vd = row[(int64_t)xd * C];
+                                max_upd<true>(best, bi, va, y * W + x);
+                                max_upd<true>(best, bi, vb, y * W + xb);
+                                max_upd<true>(best, bi, vc, y * W + xc);
+                                max_upd<true>(best, bi, vd, y * W + xd);
+                            }
+                        }
+                        sval[lane * RBINS + ph * RP + pw] = best;
+                        sidx[lane * RBINS + ph * RP + pw] = (unsigned short)bi;
+                    } else {
+                        float sum = 0.f;
+                        for (int y = hs; y < he; ++y) {
+                            const float *row = base + (int64_t)y * W * C;
+                            for (int x = ws; x < we; ++x) sum += row[(int64_t)x * C];
+                        }
+                        sval[lane * RBINS + ph * RP + pw] = sum / (float)(he - hs) / (float)(we - ws);
+                    }
+                }
+            }
+            emit();
+        }
+        STAMP(tb);
         STAMP(tc);
         STAMP_ADD(4, ta, tb); STAMP_ADD(5, tb, tc);
     }
 #ifdef DG_STAMPS
     STAMP(tk1);
     STAMP_ADD(6, tk0, tk1);
-    if (lane == 0)
+    if (lane0 == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&dg_stamp_acc[i], stamp_loc[i]);
 #endif
 }
