@@ -140,6 +140,16 @@ int dg_kmeans_labels_i32(const uint8_t *labels, int64_t n, int32_t *out, dg_stre
 int dg_rcnn_calcul_f32(const float *positive, int64_t n, const float *grt, float *t, dg_stream_t s);
 int dg_rcnn_decode_f32(const int32_t *p_rect, const float *tset, int64_t n, int variant, float *g, dg_stream_t s);
 
+/* ---------------------------------------------------------------- YOLOv1 loss, box geometry fused ("next" row 1)
+ * Loss.forward(modely, targety): yolo/yolo_v1/modules.py:234-306 -- in-loss decode :262-268, IoU :271-272,
+ * responsible-slot select :275-276, terms :283-302, combination :304-305.  modely/targety: (n,7,7,10+num_classes)
+ * fp32 contiguous.  quirk_slot2 != 0 keeps the reference's :264 (slot 2 takes its half-size from columns 5:7).
+ * loss6[0] = loss, loss6[1..5] = the xy, wh, obj, noobj, label sums.  grad (may be NULL): d loss / d modely as the
+ * reference's autograd gives it (the IoU target is not detached there), every element written. */
+size_t dg_yolo1_loss_workspace_bytes(int64_t n);
+int dg_yolo1_loss_f32(const float *modely, const float *targety, int64_t n, int64_t num_classes, int quirk_slot2,
+                      float *loss6, float *grad, void *ws, size_t ws_bytes, dg_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

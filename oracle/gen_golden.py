@@ -11,7 +11,7 @@ text is written anywhere: fixtures are data only.
     python oracle/gen_golden.py            # regenerates tests/golden/*.npz
 
 Reference symbols executed:
-  yolo/yolo_v1/modules.py : get_iou (73-98), encode (151-174), Loss.get_iou (208-228)
+  yolo/yolo_v1/modules.py : get_iou (73-98), encode (151-174), Loss (198-306: get_iou, forward + autograd)
   yolo/yolo_v1/yolo.py    : decode (115-186), nms (188-203), ap (306-367),
                             evaluate body (273-299, as text with a stub model)
   yolo/yolo_v2/utils.py   : get_point (228-234), get_iou (238-263)
@@ -80,6 +80,59 @@ def extract_lines(rel, a, b, ns, dedent=True):
 
 def base_ns():
     return {"np": np, "torch": torch, "nn": nn}
+
+
+# ------------------------------------------------------------------ YOLOv1 loss
+def _loss_inputs(seed, batch, num_classes, objects_per_image):
+    """modely with realistic + adversarial entries, targety with 1..k object cells per image."""
+    rng = np.random.default_rng(seed)
+    D = 10 + num_classes
+    out = rng.uniform(0, 1, (batch, 7, 7, D)).astype(np.float32)
+    out[..., 2:4] = rng.uniform(-0.3, 0.9, (batch, 7, 7, 2))      # negative w/h: sign*sqrt|.| and abs-area paths
+    out[..., 7:9] = rng.uniform(-0.3, 0.9, (batch, 7, 7, 2))
+    tgt = np.zeros_like(out)
+    for b in range(batch):
+        for _ in range(objects_per_image):
+            xy = rng.uniform(0.02, 0.6, 2); wh = rng.uniform(0.05, 0.38, 2)
+            lab = int(rng.integers(1, num_classes + 1))
+            t = wl.yolo1_encode(np.concatenate([xy, wh]), lab, num_classes).astype(np.float32)
+            cell = t[..., 4] > 0
+            tgt[b][cell] = t[cell]
+    # a few object cells whose predictions sit far from the target: both IoUs 0 (tie -> slot 1 is responsible)
+    obj = np.argwhere(tgt[..., 4] > 0)
+    for (b, i, j) in obj[:: max(1, len(obj) // 6)]:
+        out[b, i, j, 0:2] = [0.0, 0.0]; out[b, i, j, 2:4] = [0.001, 0.001]
+        out[b, i, j, 5:7] = [1.0, 1.0]; out[b, i, j, 7:9] = [0.001, 0.001]
+    return out, tgt
+
+
+def gen_loss():
+    ns = base_ns()
+    extract_defs("yolo/yolo_v1/modules.py", {"get_iou", "Loss"}, ns)
+    cases = {}
+    saved_cuda = torch.Tensor.cuda
+    torch.Tensor.cuda = lambda self, *a, **k: self          # Loss.__init__ moves its cell grid to the GPU; there is none here
+    try:
+        for name, (seed, batch, C, k) in {"b16c5": (3, 16, 5, 1), "b4c20": (4, 4, 20, 3), "b1c5": (5, 1, 5, 2)}.items():
+            out, tgt = _loss_inputs(seed, batch, C, k)
+            m = ns["Loss"](2, C)
+            x = torch.from_numpy(out).clone().requires_grad_(True)
+            loss = m.forward(x, torch.from_numpy(tgt).clone())
+            loss.backward()
+            cases[name + "_modely"] = out
+            cases[name + "_targety"] = tgt
+            cases[name + "_loss"] = loss.detach().numpy()
+            cases[name + "_grad"] = x.grad.numpy()
+            # same loss in float64 (tells summation-order noise from real differences)
+            x64 = torch.from_numpy(out).double().requires_grad_(True)
+            l64 = m.forward(x64, torch.from_numpy(tgt).double())
+            cases[name + "_loss_f64"] = l64.detach().numpy()
+    finally:
+        torch.Tensor.cuda = saved_cuda
+    np.savez_compressed(os.path.join(OUT, "yolo1_loss.npz"), **cases)
+    print("yolo1_loss:", {k: (v.shape if hasattr(v, "shape") else v) for k, v in cases.items() if k.endswith("_loss")},
+          [float(cases[n + "_loss"]) for n in ("b16c5", "b4c20", "b1c5")])
+
 
 
 # ------------------------------------------------------------------ IoU
@@ -385,7 +438,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(1)
-    which = sys.argv[1:] or ["iou", "nms", "decode", "roipool", "misc", "cluster"]
+    which = sys.argv[1:] or ["iou", "nms", "decode", "roipool", "misc", "cluster", "loss"]
     for w in which:
         print("generating", w, flush=True)
         globals()["gen_" + w]()

@@ -404,6 +404,107 @@ void orc_rcnn_decode_f32(const int32_t *p_rect, const float *tset, int64_t n, in
     }
 }
 
+/* ---- L1: YOLOv1 loss, box geometry fused.  yolo/yolo_v1/modules.py:234-306.
+ * y, t: (n,7,7,10+C) fp32.  Object cells: t[...,4] > 0 (:243); background: == 0 (:244).
+ *   in-loss decode :262-268   lt = cell/7 in float64 (:204-206), x1 = fp32(lt + x*(1/7) - w/2), x2 = w + x1;
+ *                             slot 2 takes its half-size from cols 5:7 (:264, kept when quirk != 0)
+ *   IoU :271-272 (module-level get_iou, eps 1e-7), responsible slot: 1 if iou1 >= iou2 else 2 (:275-276)
+ *   terms :283-302, loss = (5*(xy+wh) + obj + .5*noobj + label)/n (:304-305)
+ * comp[5] = {xy, wh, obj, noobj, label} sums in double; *loss = the combination, rounded to fp32.
+ * grad (nullable): d loss / d y as autograd gives it -- the IoU target is NOT detached in the reference, so
+ * the responsible slot's box also receives d(best IoU); min/max ties split the gradient evenly (ATen). */
+static inline float sgnf(float v) { return (v > 0.f) ? 1.f : ((v < 0.f) ? -1.f : 0.f); }
+static void l1_box(double lt, float c, float half_src, float ext, float *lo, float *hi)
+{
+    float a = c * (float)(1.0 / 7.0);
+    float hw = half_src / 2.0f;
+    *lo = (float)((lt + (double)a) - (double)hw);
+    *hi = ext + *lo;
+}
+/* IoU of pred box b against target u, and d iou / d b */
+static float l1_iou_grad(const float b[4], const float u[4], float g[4])
+{
+    float xl = fmaxf(b[0], u[0]), yt = fmaxf(b[1], u[1]), xr = fminf(b[2], u[2]), yb = fminf(b[3], u[3]);
+    float ixr = xr - xl, iyr = yb - yt;
+    float ix = ixr < 0.f ? 0.f : ixr, iy = iyr < 0.f ? 0.f : iyr;
+    float I = ix * iy;
+    float w = b[2] - b[0], h = b[3] - b[1];
+    float A1 = fabsf(w * h), A2 = fabsf((u[2] - u[0]) * (u[3] - u[1]));
+    float U = ((A1 + A2) - I) + 1e-7f;
+    float iou = I / U;
+    float gI = 1.0f / U + I / (U * U);
+    float gA = -I / (U * U);
+    float gix = (ixr < 0.f) ? 0.f : gI * iy, giy = (iyr < 0.f) ? 0.f : gI * ix;
+    float gwh = gA * sgnf(w * h);
+    float gw = gwh * h, gh = gwh * w;
+    /* xr = min(b2,u2): to b2 fully if smaller, half on a tie; xl = max(b0,u0) likewise */
+    float fx2 = (b[2] < u[2]) ? 1.f : ((b[2] == u[2]) ? 0.5f : 0.f), fx1 = (b[0] > u[0]) ? 1.f : ((b[0] == u[0]) ? 0.5f : 0.f);
+    float fy2 = (b[3] < u[3]) ? 1.f : ((b[3] == u[3]) ? 0.5f : 0.f), fy1 = (b[1] > u[1]) ? 1.f : ((b[1] == u[1]) ? 0.5f : 0.f);
+    g[0] = -gix * fx1 - gw; g[2] = gix * fx2 + gw;
+    g[1] = -giy * fy1 - gh; g[3] = giy * fy2 + gh;
+    return iou;
+}
+int orc_yolo1_loss(const float *y, const float *t, int64_t n, int C, int quirk, double *comp, float *loss, float *grad)
+{
+    const int D = 10 + C;
+    double Lxy = 0, Lwh = 0, Lobj = 0, Lno = 0, Llab = 0;
+    const float gN = 1.0f / (float)n;
+    if (grad) memset(grad, 0, sizeof(float) * (size_t)n * 49 * D);
+    for (int64_t b = 0; b < n; ++b)
+        for (int i = 0; i < 7; ++i)
+            for (int j = 0; j < 7; ++j) {
+                const int64_t o = ((b * 7 + i) * 7 + j) * D;
+                const float *p = y + o, *q = t + o;
+                float *gp = grad ? grad + o : NULL;
+                if (q[4] > 0.f) {
+                    const double ltx = (double)j * (1.0 / 7.0), lty = (double)i * (1.0 / 7.0);
+                    float b1[4], b2[4], u[4];
+                    l1_box(ltx, p[0], p[2], p[2], &b1[0], &b1[2]);
+                    l1_box(lty, p[1], p[3], p[3], &b1[1], &b1[3]);
+                    l1_box(ltx, p[5], quirk ? p[5] : p[7], p[7], &b2[0], &b2[2]);
+                    l1_box(lty, p[6], quirk ? p[6] : p[8], p[8], &b2[1], &b2[3]);
+                    l1_box(ltx, q[0], q[2], q[2], &u[0], &u[2]);
+                    l1_box(lty, q[1], q[3], q[3], &u[1], &u[3]);
+                    float g1[4], g2[4];
+                    float iou1 = l1_iou_grad(b1, u, g1), iou2 = l1_iou_grad(b2, u, g2);
+                    const int r = (iou1 >= iou2) ? 0 : 1;
+                    const float best = r ? iou2 : iou1;
+                    const float *pr = p + 5 * r;
+                    float dx = pr[0] - q[0], dy = pr[1] - q[1];
+                    Lxy += (double)(dx * dx) + (double)(dy * dy);
+                    float sw = sgnf(pr[2]) * sqrtf(fabsf(pr[2])), sh = sgnf(pr[3]) * sqrtf(fabsf(pr[3]));
+                    float dw = sw - sqrtf(q[2]), dh = sh - sqrtf(q[3]);
+                    Lwh += (double)(dw * dw) + (double)(dh * dh);
+                    float dob = best - pr[4];
+                    Lobj += (double)(dob * dob);
+                    for (int c = 10; c < D; ++c) { float d = p[c] - q[c]; Llab += (double)(d * d); }
+                    if (gp) {
+                        float *gr = gp + 5 * r;
+                        gr[0] += 10.f * dx * gN; gr[1] += 10.f * dy * gN;
+                        gr[2] += 10.f * dw * gN * (sgnf(pr[2]) * (0.5f / sqrtf(fabsf(pr[2]))) * sgnf(pr[2]));
+                        gr[3] += 10.f * dh * gN * (sgnf(pr[3]) * (0.5f / sqrtf(fabsf(pr[3]))) * sgnf(pr[3]));
+                        gr[4] += -2.f * dob * gN;
+                        const float gb = 2.f * dob * gN;            /* d loss / d best iou */
+                        const float *g = r ? g2 : g1;
+                        const float inv7 = (float)(1.0 / 7.0);
+                        for (int a = 0; a < 2; ++a) {               /* a = 0: x, 1: y */
+                            float glo = gb * g[a], ghi = gb * g[a + 2], gt = glo + ghi;
+                            if (r == 1 && quirk) { gr[a] += gt * inv7 - gt * 0.5f; gr[a + 2] += ghi; }
+                            else { gr[a] += gt * inv7; gr[a + 2] += ghi - gt * 0.5f; }
+                        }
+                        for (int c = 10; c < D; ++c) gp[c] += 2.f * (p[c] - q[c]) * gN;
+                    }
+                } else if (q[4] == 0.f) {
+                    float d4 = p[4] - q[4], d9 = p[9] - q[9];
+                    Lno += (double)(d4 * d4) + (double)(d9 * d9);
+                    if (gp) { gp[4] += d4 * gN; gp[9] += d9 * gN; }
+                }
+            }
+    if (comp) { comp[0] = Lxy; comp[1] = Lwh; comp[2] = Lobj; comp[3] = Lno; comp[4] = Llab; }
+    if (loss) *loss = (float)((5.0 * (Lxy + Lwh) + Lobj + 0.5 * Lno + Llab) / (double)n);
+    return ORC_OK;
+}
+
 /* ---- K1: 1-IoU anchor k-means.  NOT IN THE REFERENCE (clustering/cluster_prac.py:38-40
  * only fixes the sklearn-style API).  Spec, parity unpinned:
  *   d(b,c) = 1 - inter/(w*h + cw*ch - inter), inter = min(w,cw)*min(h,ch), fp32, I1 op order, no eps

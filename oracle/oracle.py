@@ -178,6 +178,17 @@ def rcnn_decode(p_rect, tset, variant=0):
     return g
 
 
+def yolo1_loss(modely, targety, quirk=True, want_grad=True):
+    """modules.py:234-306 -> (loss fp32, comp[5] float64 = xy, wh, obj, noobj, label sums, grad or None)"""
+    y = _f32(modely); t = _f32(targety)
+    n, D = y.shape[0], y.shape[-1]
+    comp = np.zeros(5, np.float64); loss = np.zeros(1, np.float32)
+    grad = np.empty_like(y) if want_grad else None
+    lib().orc_yolo1_loss(_p(y), _p(t), C.c_int64(n), C.c_int(D - 10), C.c_int(int(quirk)), _p(comp), _p(loss),
+                         _p(grad) if want_grad else None)
+    return loss[0], comp, grad
+
+
 # ------------------------------------------------------------------ proposal labelling (host logic)
 def label_proposals(rects_xywh, bbox_xywh, label, min_num, pos_thr=0.1, neg_thr=0.1, neg_quota_mult=2,
                     require_full=False):

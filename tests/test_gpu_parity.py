@@ -292,6 +292,45 @@ def test_roipool_odd_channels_and_batch(va, oracle):
             np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-6, atol=1e-7)
 
 
+# ------------------------------------------------------------------ YOLOv1 loss (fused geometry)
+def test_yolo1_loss_golden_and_autograd(va, golden, oracle):
+    from vision_amd import yolo_v1, ops
+    g = golden("yolo1_loss")
+    for name in ("b16c5", "b4c20", "b1c5"):
+        out, tgt = g[name + "_modely"], g[name + "_targety"]
+        C = out.shape[-1] - 10
+        x = torch.from_numpy(out).cuda().requires_grad_(True)
+        crit = yolo_v1.Loss(2, C)
+        loss = crit(x, torch.from_numpy(tgt).cuda())
+        (3.0 * loss).backward()
+        assert abs(loss.item() - g[name + "_loss_f64"]) <= 1e-6 * abs(g[name + "_loss_f64"]), name      # 1e-6 relative
+        np.testing.assert_allclose(x.grad.cpu().numpy(), 3.0 * g[name + "_grad"], rtol=1e-5, atol=3e-6, err_msg=name)
+        # against the oracle: same op order -> tight
+        ol, ocomp, ograd = oracle.yolo1_loss(out, tgt, quirk=True)
+        loss6, grad = ops.yolo1_loss(torch.from_numpy(out).cuda(), torch.from_numpy(tgt).cuda(), True)
+        assert abs(loss6[0].item() - ol) <= 2e-7 * abs(ol)
+        np.testing.assert_allclose(loss6[1:].cpu().numpy(), ocomp, rtol=1e-6)
+        np.testing.assert_allclose(grad.cpu().numpy(), ograd, rtol=2e-6, atol=1e-7)
+        # CPU tensors in -> CPU scalar out, like the reference
+        lc = crit(torch.from_numpy(out), torch.from_numpy(tgt))
+        assert not lc.is_cuda and abs(lc.item() - loss.item()) == 0.0
+    assert abs(yolo_v1.Loss.get_iou(yolo_v1.Loss, torch.tensor([[0., 0, 1, 1]]), torch.tensor([[0., .5, 1, 1.5]])).item() - 1 / 3) < 1e-6
+
+
+def test_yolo1_loss_large_batch_no_quirk_vs_oracle(va, oracle):
+    from vision_amd import ops
+    out, tgt = wl.yolo1_batch(21, batch=700, num_classes=20)
+    rng = np.random.default_rng(3)
+    out[..., 2:4] = rng.uniform(-0.2, 0.9, out[..., 2:4].shape)
+    tgt[5, 3, 3, 4] = -1.0                                    # neither object nor background: contributes nothing
+    for quirk in (True, False):
+        ol, ocomp, ograd = oracle.yolo1_loss(out, tgt, quirk=quirk)
+        loss6, grad = ops.yolo1_loss(torch.from_numpy(out).cuda(), torch.from_numpy(tgt).cuda(), quirk)
+        assert abs(loss6[0].item() - ol) <= 2e-7 * abs(ol), quirk
+        np.testing.assert_allclose(grad.cpu().numpy(), ograd, rtol=2e-6, atol=1e-7)
+    assert np.all(grad.cpu().numpy()[5, 3, 3] == 0)
+
+
 # ------------------------------------------------------------------ YOLOv2 / R-CNN box regression
 def test_yolo2_get_point_golden(va, golden, oracle):
     from vision_amd import yolo_v2

@@ -143,3 +143,17 @@ def test_cluster_demo_api_shape(golden):
     g = golden("cluster_demo")
     assert g["labels"].shape == (100,) and g["centers"].shape == (5, 2)
     assert set(np.unique(g["labels"])) == set(range(5))
+
+
+def test_yolo1_loss_oracle_vs_reference(golden, oracle):
+    """Loss.forward + autograd of the reference (modules.py:234-306) run on CPU by oracle/gen_golden.py.  The loss is a
+    sum of O(1e3) fp32 squares: the oracle sums in double, so it is compared with the reference's float64 run at 1e-6
+    relative (north_star's fp32 tolerance) and with its fp32 run at the fp32 summation noise; gradients at 1e-5/1e-6."""
+    g = golden("yolo1_loss")
+    for name in ("b16c5", "b4c20", "b1c5"):
+        loss, comp, grad = oracle.yolo1_loss(g[name + "_modely"], g[name + "_targety"], quirk=True)
+        assert abs(loss - g[name + "_loss_f64"]) <= 1e-6 * abs(g[name + "_loss_f64"]), name
+        assert abs(loss - g[name + "_loss"]) <= 4e-6 * abs(g[name + "_loss"]), name
+        np.testing.assert_allclose(grad, g[name + "_grad"], rtol=1e-5, atol=1e-6, err_msg=name)
+        n = g[name + "_modely"].shape[0]
+        assert abs((5 * (comp[0] + comp[1]) + comp[2] + 0.5 * comp[3] + comp[4]) / n - loss) <= 1e-6 * loss

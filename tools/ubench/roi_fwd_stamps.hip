@@ -36,7 +36,7 @@ int main(int argc, char **argv)
         hipMemcpyFromSymbol(z, HIP_SYMBOL(dg_stamp_acc), sizeof(z));
         double tot = (double)z[6];
         printf("rc=%d %.3f ms | issue %.1f%% dma-wait %.1f%% rows %.1f%% park %.1f%% | staged-total %.1f%% (stage-write %.1f%%) out-phase %.1f%% | cycles/wave %.0f\n", rc, ms,
-               100 * z[0] / tot, 100 * z[1] / tot, 100 * z[2] / tot, 100 * z[3] / tot, 100 * z[4] / tot, 100 * z[7] / tot, 100 * z[5] / tot, tot / 2048);
+               100 * z[0] / tot, 100 * z[1] / tot, 100 * z[2] / tot, 100 * z[3] / tot, 100 * (z[4] - z[5]) / tot, 100 * z[7] / tot, 100 * z[5] / tot, tot / 2048);
     }
     return 0;
 }

@@ -346,6 +346,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         // output phase; instantiated at the end of each path (staged / direct) so that the two paths do not merge
         // with 98 result registers apparently live (the allocator then carries them around the whole task loop)
         auto emit = [&]() {
+        STAMP(te0);
         __syncthreads();
         // contiguous run of cvalid*49 outputs for this (roi, channel block)
         const int64_t obase = (roi * C + c0) * RBINS;
@@ -396,6 +397,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             }
         }
         __syncthreads();      // the buffer is reused by the next task's ring
+        STAMP(te1);
+        STAMP_ADD(5, te0, te1);
         };
         bool staged = false;
         if (MODE == DG_POOL_MAX) {
@@ -491,8 +494,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             emit();
         }
         STAMP(tb);
-        STAMP(tc);
-        STAMP_ADD(4, ta, tb); STAMP_ADD(5, tb, tc);
+        STAMP_ADD(4, ta, tb);                                 // whole task; slot 5 (output phase) is part of it
     }
 #ifdef DG_STAMPS
     STAMP(tk1);

@@ -100,6 +100,23 @@ def yolo1_decode_batched(output, target=None, conf_threshold=0.2, prob_threshold
     return box, label, conf, score, count, tbox, tlabel
 
 
+# ------------------------------------------------------------------ YOLOv1 loss (fused geometry)
+def yolo1_loss(modely, targety, quirk_slot2=True, want_grad=True):
+    """(n,7,7,10+C) fp32 x2 -> (loss6 device tensor [loss, xy, wh, obj, noobj, label], grad or None)."""
+    dev = _abi.device_of(modely, targety)
+    y, t = _f32c(modely, dev), _f32c(targety, dev)
+    if y.dim() != 4 or tuple(y.shape[1:3]) != (7, 7) or y.shape[3] < 10 or y.shape != t.shape:
+        raise ValueError("Loss: modely/targety must both be (n,7,7,10+C)")
+    n, C_ = y.shape[0], y.shape[3] - 10
+    loss6 = torch.empty((6,), dtype=torch.float32, device=dev)
+    grad = torch.empty_like(y) if want_grad else None
+    nbytes = load().dg_yolo1_loss_workspace_bytes(n)
+    ws = workspace(dev, nbytes)
+    with torch.cuda.device(dev):
+        check(load().dg_yolo1_loss_f32(ptr(y), ptr(t), n, C_, int(quirk_slot2), ptr(loss6), ptr(grad), ptr(ws), nbytes, stream_ptr(dev)))
+    return loss6, grad
+
+
 # ------------------------------------------------------------------ RoI pooling
 def roi_windows(rois, roi_idx, B, H, W, dev):
     r = _abi.to_dev(rois, torch.float64, dev).reshape(-1, 4)

@@ -3,6 +3,7 @@ reference; the arithmetic runs in HIP kernels on the MI355X).
 
   get_iou(bb1, bb2)                       yolo/yolo_v1/modules.py:73-98
   Loss.get_iou(self, bb1, bb2)            yolo/yolo_v1/modules.py:208-228   (eps 1e-6)
+  Loss(num_bboxes, num_classes)(modely, targety)   yolo/yolo_v1/modules.py:234-306   (fused forward + gradient)
   decode(output, target, conf_threshold, prob_threshold)   yolo/yolo_v1/yolo.py:115-186
   nms(out_box, out_score, threshold)      yolo/yolo_v1/yolo.py:188-203
   evaluate_batch(...)                     yolo/yolo_v1/yolo.py:273-299 after the model call
@@ -25,16 +26,43 @@ def get_iou(bb1, bb2):
     return _back(ops.iou_elementwise(bb1, bb2, 1e-7), bb1)
 
 
-class Loss:
-    """Only the geometry of the reference's Loss module (modules.py:198-228)."""
+class _Yolo1LossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, modely, targety, quirk):
+        loss6, grad = ops.yolo1_loss(modely.detach(), targety, quirk, want_grad=modely.requires_grad)
+        ctx.grad = grad
+        ctx.in_device, ctx.in_dtype = modely.device, modely.dtype
+        ctx.components = loss6[1:]
+        return loss6[0].to(modely.device) if not modely.is_cuda else loss6[0]
 
-    def __init__(self, num_bboxes=2, num_classes=5):
+    @staticmethod
+    def backward(ctx, gout):
+        g = ctx.grad * gout.to(ctx.grad.device)
+        return g.to(device=ctx.in_device, dtype=ctx.in_dtype), None, None
+
+
+class Loss(torch.nn.Module):
+    """Reference Loss (modules.py:198-306) with the forward pass -- in-loss decode, IoU, responsible-box select,
+    the five terms -- and its gradient fused into one HIP kernel.  `quirk_slot2=True` keeps modules.py:264
+    (slot 2's half-size read from columns 5:7); the IoU target is not detached, as in the reference."""
+
+    def __init__(self, num_bboxes=2, num_classes=5, quirk_slot2=True):
+        super().__init__()
+        if num_bboxes != 2:
+            raise ValueError("Loss: the reference's geometry is written for 2 boxes per cell (modules.py:253-265)")
         self.S = 7
         self.num_bboxes = num_bboxes
         self.num_classes = num_classes
+        self.quirk_slot2 = quirk_slot2
 
     def get_iou(self, bb1, bb2):
         return _back(ops.iou_elementwise(bb1, bb2, 1e-6), bb1)
+
+    def forward(self, modely, targety):
+        modely = torch.as_tensor(modely)
+        if modely.shape[-1] != 5 * self.num_bboxes + self.num_classes:
+            raise ValueError("Loss: last dimension must be 5*num_bboxes + num_classes")
+        return _Yolo1LossFn.apply(modely, torch.as_tensor(targety), self.quirk_slot2)
 
 
 def decode(output, target, conf_threshold=0.2, prob_threshold=0.1):
