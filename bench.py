@@ -50,10 +50,16 @@ class Dist:
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
         if self.world != n and self.world > 1:
             raise SystemExit(f"--gpus {n} but WORLD_SIZE={self.world}")
-        torch.cuda.set_device(self.local)
-        self.dev = torch.device("cuda", self.local)
+        # DG_BENCH_REHEARSE=1: every rank on cuda:0 with gloo -- a functional rehearsal of the N>1 path on a one-GPU box
+        rehearse = self.rehearse = os.environ.get("DG_BENCH_REHEARSE") == "1"
+        dev_index = 0 if rehearse else self.local
+        torch.cuda.set_device(dev_index)
+        self.dev = torch.device("cuda", dev_index)
         if self.world > 1:
-            dist.init_process_group("nccl", device_id=self.dev)
+            if rehearse:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=self.dev)
 
     def barrier(self):
         if self.world > 1:
@@ -63,7 +69,7 @@ class Dist:
     def max(self, x):
         if self.world == 1:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device=self.dev)
+        t = torch.tensor([x], dtype=torch.float64, device="cpu" if self.rehearse else self.dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -231,7 +237,7 @@ def extra_kmeans(d, n_total=10_000_000, iters=30):
     per = hi - lo
     shard = torch.from_numpy(wh_all[lo:hi]).to(d.dev)
     del wh_all
-    km = cluster.kmean(5, 42)
+    km = cluster.kmean(5, 42, reduce_device="cpu" if d.rehearse else None)   # rehearsal: gloo reduces host tensors
     km.fit(shard, init_centers=init, fixed_iters=iters)     # warm-up (RCCL channels, workspace); leaves the device state
     sec = Dist.timed(d, lambda: km._run_iters(0, iters), 1, 0)   # the Lloyd iterations proper (step [+ all-reduce] + update)
     # kernel-only rate of the step on this shard
@@ -242,6 +248,14 @@ def extra_kmeans(d, n_total=10_000_000, iters=30):
             "centers": km.cluster_centers_.round(6).tolist(),
             "note": "config 4, strong scaling: 10M boxes sharded, one 17 x int64 all-reduce per iteration; "
                     "timed: 30 iterations of step [+ all-reduce] + centroid update, device-resident"}
+
+
+T0 = time.perf_counter()
+
+
+def trace(d, msg):
+    if os.environ.get("DG_BENCH_TRACE") == "1":
+        print(f"[bench rank {d.rank} t={time.perf_counter() - T0:7.2f}s] {msg}", file=sys.stderr, flush=True)
 
 
 def main():
@@ -257,8 +271,11 @@ def main():
     from vision_amd import _abi
     _abi.load()
 
+    trace(d, "init done")
     w = FrcnnBatch(d, a.images)
+    trace(d, "workload resident")
     sec = d.timed(w.step, a.steps, a.warmup)
+    trace(d, "timed region done")
     w.check()
     total_rois = a.images * w.n_rois
     ms_step = sec / a.steps * 1e3
@@ -292,8 +309,10 @@ def main():
             extra["config2_yolo1_b64"] = extra_yolo(d)
             extra["config5_stress_64k"] = extra_stress(d)
             torch.cuda.empty_cache()
+        trace(d, "extras on rank 0 done / waiting")
         d.barrier()
         extra["config4_kmeans_10M"] = extra_kmeans(d)
+        trace(d, "k-means done")
     cpu = None
     if d.rank == 0 and d.world == 1 and not a.no_cpu:
         cpu = cpu_baseline_frcnn()
@@ -307,8 +326,18 @@ def main():
                            "global_batch_images": a.images, "rois_per_image": 2000, "parallelism": f"image-shard x{d.world}"},
                 "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
         print(json.dumps(line))
+    sys.stdout.flush()
     if d.world > 1:
-        dist.destroy_process_group()
+        # leave together; a teardown that does not come back within 30 s must not hold the whole job
+        import threading
+        d.barrier()
+        trace(d, "final barrier passed")
+        t = threading.Thread(target=dist.destroy_process_group, daemon=True)
+        t.start()
+        t.join(30.0)
+        trace(d, "process group destroyed" if not t.is_alive() else "destroy_process_group still running: exiting anyway")
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":
