@@ -150,6 +150,12 @@ size_t dg_yolo1_loss_workspace_bytes(int64_t n);
 int dg_yolo1_loss_f32(const float *modely, const float *targety, int64_t n, int64_t num_classes, int quirk_slot2,
                       float *loss6, float *grad, void *ws, size_t ws_bytes, dg_stream_t s);
 
+/* YOLOv1 target encoder, batched ("next" row 4).  encode(bb,label,num_classes): yolo/yolo_v1/modules.py:151-174.
+ * bb (n,4) float64 {left, top, w, h}; label (n) int64 in 1..num_classes; target (n,7,7,10+num_classes) float64, fully
+ * written.  *status (caller zeroes it): bit 0 = cell index outside [-7,7) (NumPy IndexError), bit 1 = bad label. */
+int dg_yolo1_encode_f64(const double *bb, const int64_t *label, int64_t n, int64_t num_classes, double *target,
+                        int32_t *status, dg_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

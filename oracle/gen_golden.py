@@ -106,6 +106,26 @@ def _loss_inputs(seed, batch, num_classes, objects_per_image):
     return out, tgt
 
 
+def gen_encode():
+    ns = extract_defs("yolo/yolo_v1/modules.py", {"encode"}, base_ns())
+    rng = np.random.default_rng(8)
+    bbs, labs, tgts, centres = [], [], [], []
+    for k in range(40):
+        C = 5 if k < 30 else 20
+        bb = np.concatenate([rng.uniform(0.0, 0.62, 2), rng.uniform(0.02, 0.38, 2)])
+        if k == 7:
+            bb = np.array([0.0, 0.0, 2.0 / 7.0, 2.0 / 7.0])        # centre exactly on a cell corner
+        lab = int(rng.integers(1, C + 1))
+        b2 = bb.copy()
+        t = ns["encode"](b2, lab, C)
+        bbs.append(bb); labs.append(lab); centres.append(b2)
+        tgts.append(t if C == 5 else None)
+        if C == 20:
+            tgts[-1] = t
+    np.savez_compressed(os.path.join(OUT, "yolo1_encode.npz"), bb=np.array(bbs), label=np.array(labs, np.int64),
+                        bb_after=np.array(centres), target_c5=np.array(tgts[:30]), target_c20=np.array(tgts[30:]))
+
+
 def gen_loss():
     ns = base_ns()
     extract_defs("yolo/yolo_v1/modules.py", {"get_iou", "Loss"}, ns)
@@ -438,7 +458,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(1)
-    which = sys.argv[1:] or ["iou", "nms", "decode", "roipool", "misc", "cluster", "loss"]
+    which = sys.argv[1:] or ["iou", "nms", "decode", "roipool", "misc", "cluster", "loss", "encode"]
     for w in which:
         print("generating", w, flush=True)
         globals()["gen_" + w]()

@@ -292,6 +292,21 @@ def test_roipool_odd_channels_and_batch(va, oracle):
             np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-6, atol=1e-7)
 
 
+def test_yolo1_encode_golden(va, golden):
+    from vision_amd import yolo_v1
+    g = golden("yolo1_encode")
+    t5 = yolo_v1.encode_batched(g["bb"][:30], g["label"][:30], 5, dtype=torch.float64)
+    t20 = yolo_v1.encode_batched(torch.from_numpy(g["bb"][30:]).cuda(), g["label"][30:], 20, dtype=torch.float64)
+    assert t5.is_cuda and np.array_equal(t5.cpu().numpy(), g["target_c5"]) and np.array_equal(t20.cpu().numpy(), g["target_c20"])
+    bb = g["bb"][3].copy()
+    one = yolo_v1.encode(bb, int(g["label"][3]), 5)
+    assert one.dtype == np.float64 and np.array_equal(one, g["target_c5"][3]) and np.array_equal(bb, g["bb_after"][3])
+    with pytest.raises(IndexError):
+        yolo_v1.encode(np.array([0.9, 0.9, 0.4, 0.4]), 1, 5)          # centre in cell 7: NumPy raises too
+    with pytest.raises(IndexError):
+        yolo_v1.encode(np.array([0.1, 0.1, 0.2, 0.2]), 6, 5)
+
+
 # ------------------------------------------------------------------ YOLOv1 loss (fused geometry)
 def test_yolo1_loss_golden_and_autograd(va, golden, oracle):
     from vision_amd import yolo_v1, ops

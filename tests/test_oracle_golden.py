@@ -157,3 +157,13 @@ def test_yolo1_loss_oracle_vs_reference(golden, oracle):
         np.testing.assert_allclose(grad, g[name + "_grad"], rtol=1e-5, atol=1e-6, err_msg=name)
         n = g[name + "_modely"].shape[0]
         assert abs((5 * (comp[0] + comp[1]) + comp[2] + 0.5 * comp[3] + comp[4]) / n - loss) <= 1e-6 * loss
+
+
+def test_yolo1_encode_restatement_vs_reference(golden):
+    """workloads.yolo1_encode (the NumPy restatement used for synthetic targets) against the reference's encode."""
+    from vision_amd import workloads as wl
+    g = golden("yolo1_encode")
+    for k in range(len(g["bb"])):
+        C = 5 if k < 30 else 20
+        want = g["target_c5"][k] if k < 30 else g["target_c20"][k - 30]
+        assert np.array_equal(wl.yolo1_encode(g["bb"][k], int(g["label"][k]), C), want), k

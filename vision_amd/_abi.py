@@ -47,6 +47,7 @@ SIGNATURES = {
     "dg_kmeans_labels_i32": (C.c_int, [_vp, _i64, _vp, _vp]),
     "dg_rcnn_calcul_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "dg_rcnn_decode_f32": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, _vp]),
+    "dg_yolo1_encode_f64": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "dg_yolo1_loss_workspace_bytes": (C.c_size_t, [_i64]),
     "dg_yolo1_loss_f32": (C.c_int, [_vp, _vp, _i64, _i64, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp]),
 }

@@ -255,3 +255,48 @@ extern "C" int dg_rcnn_decode_f32(const int32_t *p_rect, const float *tset, int6
     DG_CHECK_LAUNCH("k_rcnn_decode");
     return DG_OK;
 }
+
+// ---------------------------------------------------------------- YOLOv1 target encoder ("next" row 4)
+// encode(bb,label,num_classes): yolo/yolo_v1/modules.py:151-174, float64 like NumPy.  bb = {left, top, w, h} relative
+// to the image; the object's cell gets [x_cell, y_cell, w, h, 1] in both box slots and a one-hot class.
+// One thread per box writes its cell (the target was zeroed by the caller's memset).  status: bit 0 = a cell index
+// outside [-7,7) (NumPy raises IndexError), bit 1 = label outside 1..C.
+__global__ __launch_bounds__(256) void k_yolo1_encode(const double *__restrict__ bb, const int64_t *__restrict__ label, int64_t n,
+                                                      int C, double *__restrict__ target, int32_t *__restrict__ status)
+{
+    const int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (b >= n) return;
+    const int D = 10 + C;
+    const double cell = 1.0 / 7.0;
+    const double w = bb[4 * b + 2], h = bb[4 * b + 3];
+    const double cx = bb[4 * b] + w / 2, cy = bb[4 * b + 1] + h / 2;
+    int i = (int)(cx * 7), j = (int)(cy * 7);              // astype(int): truncation
+    const double xc = (cx - (double)i * cell) / cell, yc = (cy - (double)j * cell) / cell;
+    const int64_t lab = label[b];
+    int bad = 0;
+    if (i < -7 || i >= 7 || j < -7 || j >= 7) bad |= 1;
+    if (lab < 1 || lab > C) bad |= 2;
+    if (bad) { atomicOr(status, bad); return; }
+    if (i < 0) i += 7;                                       // NumPy negative index
+    if (j < 0) j += 7;
+    double *t = target + ((b * 7 + j) * 7 + i) * D;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) { t[5 * s2] = xc; t[5 * s2 + 1] = yc; t[5 * s2 + 2] = w; t[5 * s2 + 3] = h; t[5 * s2 + 4] = 1.0; }
+    t[10 + lab - 1] = 1.0;
+}
+
+extern "C" int dg_yolo1_encode_f64(const double *bb, const int64_t *label, int64_t n, int64_t num_classes, double *target,
+                                   int32_t *status, dg_stream_t s)
+{
+    DG_REQUIRE(n >= 0 && num_classes >= 1 && num_classes <= 4096, "yolo1_encode: bad shape");
+    if (n == 0) return DG_OK;
+    DG_REQUIRE(bb && label && target && status, "yolo1_encode: null pointer");
+    hipStream_t st = (hipStream_t)s;
+    if (hipMemsetAsync(target, 0, (size_t)n * 49 * (10 + num_classes) * sizeof(double), st) != hipSuccess) {
+        dg_set_error("yolo1_encode: memset failed");
+        return DG_EHIP;
+    }
+    hipLaunchKernelGGL(k_yolo1_encode, dim3((unsigned)dg_cdiv(n, 256)), dim3(256), 0, st, bb, label, n, (int)num_classes, target, status);
+    DG_CHECK_LAUNCH("k_yolo1_encode");
+    return DG_OK;
+}

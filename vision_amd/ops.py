@@ -100,6 +100,21 @@ def yolo1_decode_batched(output, target=None, conf_threshold=0.2, prob_threshold
     return box, label, conf, score, count, tbox, tlabel
 
 
+def yolo1_encode_batched(bb, label, num_classes):
+    """bb (n,4) {left, top, w, h}, label (n) in 1..C -> target (n,7,7,10+C) float64 on the GPU (modules.py:151-174)."""
+    dev = _abi.device_of(bb, label)
+    b = _abi.to_dev(bb, torch.float64, dev).reshape(-1, 4)
+    l = _abi.to_dev(label, torch.int64, dev).reshape(-1)
+    if l.shape[0] != b.shape[0]:
+        raise ValueError("encode: one label per box")
+    n = b.shape[0]
+    target = torch.empty((n, 7, 7, 10 + num_classes), dtype=torch.float64, device=dev)
+    status = torch.zeros((1,), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(load().dg_yolo1_encode_f64(ptr(b), ptr(l), n, num_classes, ptr(target), ptr(status), stream_ptr(dev)))
+    return target, status
+
+
 # ------------------------------------------------------------------ YOLOv1 loss (fused geometry)
 def yolo1_loss(modely, targety, quirk_slot2=True, want_grad=True):
     """(n,7,7,10+C) fp32 x2 -> (loss6 device tensor [loss, xy, wh, obj, noobj, label], grad or None)."""

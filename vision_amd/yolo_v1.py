@@ -4,6 +4,7 @@ reference; the arithmetic runs in HIP kernels on the MI355X).
   get_iou(bb1, bb2)                       yolo/yolo_v1/modules.py:73-98
   Loss.get_iou(self, bb1, bb2)            yolo/yolo_v1/modules.py:208-228   (eps 1e-6)
   Loss(num_bboxes, num_classes)(modely, targety)   yolo/yolo_v1/modules.py:234-306   (fused forward + gradient)
+  encode(bb, label, num_classes)          yolo/yolo_v1/modules.py:151-174   (+ encode_batched)
   decode(output, target, conf_threshold, prob_threshold)   yolo/yolo_v1/yolo.py:115-186
   nms(out_box, out_score, threshold)      yolo/yolo_v1/yolo.py:188-203
   evaluate_batch(...)                     yolo/yolo_v1/yolo.py:273-299 after the model call
@@ -63,6 +64,28 @@ class Loss(torch.nn.Module):
         if modely.shape[-1] != 5 * self.num_bboxes + self.num_classes:
             raise ValueError("Loss: last dimension must be 5*num_bboxes + num_classes")
         return _Yolo1LossFn.apply(modely, torch.as_tensor(targety), self.quirk_slot2)
+
+
+def encode(bb, label, num_classes):
+    """Target builder (modules.py:151-174): bb = {left, top, w, h} -> (7,7,10+C) float64 ndarray.  Like the reference it
+    turns `bb[:2]` into the box centre IN PLACE when bb is an ndarray."""
+    src = np.array(bb, np.float64)
+    target, status = ops.yolo1_encode_batched(src.reshape(1, 4), np.array([label], np.int64), num_classes)
+    st = int(status.item())
+    if st:
+        raise IndexError("encode: box centre outside the 7x7 grid" if st & 1 else "encode: label outside 1..num_classes")
+    if isinstance(bb, np.ndarray):
+        bb[:2] += bb[2:] / 2
+    return target[0].cpu().numpy()
+
+
+def encode_batched(bbs, labels, num_classes, dtype=torch.float32):
+    """(n,4) boxes + (n) labels -> (n,7,7,10+C) targets on the GPU in one launch (what a collate step would call)."""
+    target, status = ops.yolo1_encode_batched(bbs, labels, num_classes)
+    st = int(status.item())
+    if st:
+        raise IndexError("encode: box centre outside the 7x7 grid" if st & 1 else "encode: label outside 1..num_classes")
+    return target.to(dtype)
 
 
 def decode(output, target, conf_threshold=0.2, prob_threshold=0.1):
