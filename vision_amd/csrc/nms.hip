@@ -23,6 +23,12 @@ struct NmsWs {
     float *x1, *y1, *x2, *y2, *area;
     int32_t *order;
     u64 *mask, *rsum;
+    // compact form of the mask for 64 < W <= 1024 (see k_nms_csr_*): per 64-row block a contiguous run of
+    // (row-in-block << 16 | word, bits) entries for the non-zero words right of the diagonal
+    int64_t ecap;            // entries per image the workspace holds
+    int32_t *bcnt, *boff, *cursor, *cflag;
+    u32 *ekey;
+    u64 *eval;
     size_t total;
 };
 
@@ -47,6 +53,13 @@ static NmsWs nms_layout(int64_t batch, int64_t nmax, void *base)
     w.order = (int32_t *)take((size_t)batch * w.Np * 4);
     w.mask = (u64 *)take((size_t)batch * w.Np * w.W * 8);
     w.rsum = (u64 *)take((size_t)batch * w.Np * w.SW * 8);
+    w.ecap = (w.W > 64 && w.W <= 1024) ? w.Np * 32 : 0;
+    w.bcnt = (int32_t *)take((size_t)batch * w.W * 4);
+    w.boff = (int32_t *)take((size_t)batch * (w.W + 1) * 4);
+    w.cursor = (int32_t *)take((size_t)batch * w.W * 4);
+    w.cflag = (int32_t *)take((size_t)batch * 4);
+    w.ekey = (u32 *)take((size_t)batch * (w.ecap + 8) * 4);      // + CSR_SLACK
+    w.eval = (u64 *)take((size_t)batch * (w.ecap + 8) * 8);
     w.total = off;
     return w;
 }
@@ -393,8 +406,10 @@ template <int T>
 __global__ __launch_bounds__(T) void k_nms_reduce_sum(const u64 *__restrict__ mask, const u64 *__restrict__ rsum,
                                                       const int32_t *__restrict__ order, const int32_t *__restrict__ counts,
                                                       int64_t nmax, int64_t Np, int64_t W, int64_t SW, int quirk,
-                                                      int64_t *__restrict__ keep, int32_t *__restrict__ keep_count)
+                                                      int64_t *__restrict__ keep, int32_t *__restrict__ keep_count,
+                                                      const int32_t *__restrict__ cflag)
 {
+    if (cflag && cflag[blockIdx.x]) return;                   // k_nms_reduce_csr does this image
     static_assert(T == 1024, "thread <-> (row, summary word) mapping assumes 1024 threads");
     extern __shared__ u64 nms_lds[];
     __shared__ u64 sumring[2][64][16];
@@ -525,6 +540,296 @@ __global__ __launch_bounds__(T) void k_nms_reduce_sum(const u64 *__restrict__ ma
     if (tid == 0) keep_count[img] = total;
 }
 
+// ---------------------------------------------------------------- compact mask + LDS-fed reduce (64 < W <= 1024)
+// k_nms_reduce_sum pays one HBM round trip per 64-row block (about 2 us): the words it needs are only known once the
+// block is resolved.  Here the non-zero words right of the diagonal are first gathered, per block, into one contiguous
+// run of (row-in-block << 16 | word, bits) entries -- a few MB in all -- which does not depend on what is kept.  The
+// reduce fetches each block's run, diagonal words and order 8 blocks ahead into registers (one entry per thread) and
+// publishes them into an LDS double buffer one block ahead, so the serial chain touches LDS only.  A set too dense for the entry
+// capacity (32 per row on average) keeps the summary-driven kernel: cflag says which of the two runs.
+#define CSR_LDS_ENTRIES 1024     // entries of a block's run the reduce holds in LDS (one per thread); the rest is read from memory
+#define CSR_AHEAD 8              // blocks fetched ahead into registers
+#define CSR_SLACK 8              // readable entries past the last run
+__device__ __forceinline__ u64 csr_live_bits(u64 sumword, int s, int ib)   // summary bits of words > ib
+{
+    const int d = ib - s * 64;
+    if (d < 0) return sumword;
+    if (d >= 63) return 0ull;
+    return sumword & ~((2ull << d) - 1ull);
+}
+
+// one wave = the 64 rows of one block: bcnt[block] = number of entries
+__global__ __launch_bounds__(256) void k_nms_csr_count(const u64 *__restrict__ rsum, const int32_t *__restrict__ counts, int64_t nmax,
+                                                       int64_t Np, int64_t W, int64_t SW, int32_t *__restrict__ bcnt)
+{
+    const int img = blockIdx.y;
+    const int n = counts ? counts[img] : (int)nmax;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // row; Np is a multiple of 64
+    if (i >= Np) return;
+    const int ib = (int)(i >> 6);
+    const int nb = (n + 63) >> 6, SWn = (nb + 63) >> 6;
+    int c = 0;
+    if (i < n)
+        for (int s = ib >> 6; s < SWn; ++s) c += __builtin_popcountll(csr_live_bits(rsum[((int64_t)img * Np + i) * SW + s], s, ib));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
+    if ((threadIdx.x & 63) == 0) bcnt[(int64_t)img * W + ib] = c;
+}
+
+// one workgroup per image: exclusive scan of the block counts; cflag = the entries fit
+__global__ __launch_bounds__(1024) void k_nms_csr_scan(const int32_t *__restrict__ bcnt, const int32_t *__restrict__ counts, int64_t nmax,
+                                                       int64_t W, int64_t ecap, int32_t *__restrict__ boff, int32_t *__restrict__ cursor,
+                                                       int32_t *__restrict__ cflag)
+{
+    __shared__ int64_t sc[1024];
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const int n = counts ? counts[img] : (int)nmax;
+    const int nb = (n + 63) >> 6;                                    // <= 1024 here
+    const int64_t v = (tid < nb) ? bcnt[(int64_t)img * W + tid] : 0;
+    sc[tid] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int64_t a = (tid >= o) ? sc[tid - o] : 0;
+        __syncthreads();
+        sc[tid] += a;
+        __syncthreads();
+    }
+    const int64_t total = sc[1023];
+    const bool fits = total <= ecap;
+    if (tid < nb) {
+        const int32_t o = fits ? (int32_t)(sc[tid] - v) : 0;
+        boff[(int64_t)img * (W + 1) + tid] = o;
+        cursor[(int64_t)img * W + tid] = o;
+    }
+    if (tid == 0) {
+        boff[(int64_t)img * (W + 1) + nb] = fits ? (int32_t)total : 0;
+        cflag[img] = fits ? 1 : 0;
+    }
+}
+
+// thread = (row, summary word): copies its non-zero words right of the diagonal into the block's run
+__global__ __launch_bounds__(256) void k_nms_csr_fill(const u64 *__restrict__ mask, const u64 *__restrict__ rsum,
+                                                      const int32_t *__restrict__ counts, int64_t nmax, int64_t Np, int64_t W,
+                                                      int64_t SW, int64_t ecap, const int32_t *__restrict__ cflag,
+                                                      int32_t *__restrict__ cursor, u32 *__restrict__ ekey, u64 *__restrict__ eval)
+{
+    const int img = blockIdx.y;
+    if (!cflag[img]) return;
+    const int n = counts ? counts[img] : (int)nmax;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = t / SW;
+    const int s = (int)(t - i * SW);
+    if (i >= n) return;
+    const int ib = (int)(i >> 6), r = (int)(i & 63);
+    if (s < (ib >> 6)) return;
+    u64 bits = csr_live_bits(rsum[((int64_t)img * Np + i) * SW + s], s, ib);
+    const int c = __builtin_popcountll(bits);
+    if (!c) return;
+    int64_t pos = (int64_t)img * (ecap + CSR_SLACK) + atomicAdd(&cursor[(int64_t)img * W + ib], c);
+    // (the 64 threads of a wave are 64/SW consecutive rows: when SW divides 64 they share one block counter, but the
+    //  per-thread atomic is kept simple; k_nms_csr_fill_wave below is the aggregated form used when that holds)
+    const u64 *mrow = mask + ((int64_t)img * Np + i) * W;
+    while (bits) {
+        const int w = s * 64 + __builtin_ctzll(bits);
+        bits &= bits - 1;
+        ekey[pos] = ((u32)r << 16) | (u32)w;
+        eval[pos] = mrow[w];
+        ++pos;
+    }
+}
+
+// same, for SW a power of two <= 64: a wave covers 64/SW whole rows of ONE block, so it reserves its entries with a
+// single atomic (lane prefix sums by shuffles) instead of one atomic per thread on the same counter
+__global__ __launch_bounds__(256) void k_nms_csr_fill_wave(const u64 *__restrict__ mask, const u64 *__restrict__ rsum,
+                                                           const int32_t *__restrict__ counts, int64_t nmax, int64_t Np, int64_t W,
+                                                           int64_t SW, int sw_shift, int64_t ecap, const int32_t *__restrict__ cflag,
+                                                           int32_t *__restrict__ cursor, u32 *__restrict__ ekey, u64 *__restrict__ eval)
+{
+    const int img = blockIdx.y;
+    if (!cflag[img]) return;
+    const int n = counts ? counts[img] : (int)nmax;
+    const int lane = threadIdx.x & 63;
+    const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t i = t >> sw_shift;
+    const int s = (int)(t & (SW - 1));
+    const int64_t i0 = (t - lane) >> sw_shift;                   // first row of this wave (uniform)
+    if (i0 >= n) return;
+    const int ib = (int)(i0 >> 6), r = (int)(i & 63);
+    u64 bits = 0;
+    if (i < n && s >= (ib >> 6)) bits = csr_live_bits(rsum[((int64_t)img * Np + i) * SW + s], s, ib);
+    const int c = __builtin_popcountll(bits);
+    int incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const int up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+    }
+    const int wave_total = __shfl(incl, 63, 64);
+    if (wave_total == 0) return;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&cursor[(int64_t)img * W + ib], wave_total);
+    base = __shfl(base, 0, 64);
+    int64_t pos = (int64_t)img * (ecap + CSR_SLACK) + base + (incl - c);
+    const u64 *mrow = mask + ((int64_t)img * Np + i) * W;
+    while (bits) {
+        const int w = s * 64 + __builtin_ctzll(bits);
+        bits &= bits - 1;
+        ekey[pos] = ((u32)r << 16) | (u32)w;
+        eval[pos] = mrow[w];
+        ++pos;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_nms_reduce_csr(const u64 *__restrict__ mask, const int32_t *__restrict__ order,
+                                                         const int32_t *__restrict__ counts, int64_t nmax, int64_t Np, int64_t W,
+                                                         int64_t ecap, const int32_t *__restrict__ cflag, const int32_t *__restrict__ boff,
+                                                         const u32 *__restrict__ ekey, const u64 *__restrict__ eval, int quirk,
+                                                         int64_t *__restrict__ keep, int32_t *__restrict__ keep_count)
+{
+    __shared__ u64 remv[1024];
+    __shared__ __attribute__((aligned(16))) u64 s_val[2][CSR_LDS_ENTRIES];
+    __shared__ __attribute__((aligned(16))) u32 s_key[2][CSR_LDS_ENTRIES];
+    __shared__ u64 s_diag[2][64];
+    __shared__ int32_t s_order[2][64];
+    __shared__ int s_len[2], s_new[2];
+    __shared__ int32_t s_boff[1025];                          // block offsets: read every iteration, keep them out of the memory path
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (!cflag[img]) return;                                  // too dense: k_nms_reduce_sum does this image
+    const int n = counts ? counts[img] : (int)nmax;
+    mask += (int64_t)img * Np * W;
+    order += (int64_t)img * Np;
+    keep += (int64_t)img * nmax;
+    boff += (int64_t)img * (W + 1);
+    ekey += (int64_t)img * (ecap + CSR_SLACK);
+    eval += (int64_t)img * (ecap + CSR_SLACK);
+    const int nb = (n + 63) >> 6;
+    for (int w = tid; w < (int)W; w += 1024) {
+        const int64_t base = (int64_t)w * 64;
+        remv[w] = (base >= n) ? ~0ull : ((n - base >= 64) ? 0ull : (~0ull << (n - base)));
+    }
+    for (int w = tid; w <= nb; w += 1024) s_boff[w] = boff[w];
+    if (tid < 2) s_new[tid] = 0;
+    __syncthreads();
+
+    // Every thread carries ONE entry of each of the next CSR_AHEAD blocks in registers (wave 0 also their diagonal words
+    // and order): register slot b % CSR_AHEAD holds block b from CSR_AHEAD iterations before it is needed until it is
+    // published into the LDS double buffer, one iteration before.  The block loop is unrolled by CSR_AHEAD so that the
+    // slots are plain registers.  Only the lanes that have an entry load one (a run is a few hundred entries).
+    u32 hkey[CSR_AHEAD];
+    u64 hval[CSR_AHEAD], hdiag[CSR_AHEAD];
+    int32_t hord[CSR_AHEAD];
+    int hlen[CSR_AHEAD];
+#pragma unroll
+    for (int j = 0; j < CSR_AHEAD; ++j) { hkey[j] = 0; hval[j] = 0; hdiag[j] = 0; hord[j] = 0; hlen[j] = 0; }
+    auto fetch = [&](int j, int b) {
+        if (b >= nb) return;
+        const int o = s_boff[b], len = s_boff[b + 1] - o;
+        hlen[j] = len;
+        hkey[j] = (tid < len) ? ekey[o + tid] : 0u;
+        hval[j] = (tid < len) ? eval[o + tid] : 0ull;
+        if (wave == 0) { hdiag[j] = mask[((int64_t)b * 64 + lane) * W + b]; hord[j] = order[b * 64 + lane]; }
+    };
+    auto publish = [&](int j, int slot) {
+        s_key[slot][tid] = hkey[j];
+        s_val[slot][tid] = hval[j];
+        if (wave == 0) { s_diag[slot][lane] = hdiag[j]; s_order[slot][lane] = hord[j]; }
+        if (tid == 0) s_len[slot] = hlen[j];
+    };
+#pragma unroll
+    for (int j = 0; j < CSR_AHEAD; ++j) fetch(j, j);
+    if (nb > 0) { publish(0, 0); fetch(0, CSR_AHEAD); }
+    __syncthreads();
+
+    int total = 0, last_r = 0, last_new = 0, any_kept = 0;
+    u64 last_curb = 0;
+    for (int ib0 = 0; ib0 < nb; ib0 += CSR_AHEAD) {
+#pragma unroll
+      for (int jj = 0; jj < CSR_AHEAD; ++jj) {
+        const int ib = ib0 + jj;
+        if (ib >= nb) break;
+        const int slot = ib & 1;
+        u64 cur = uniform64(remv[ib]);
+        const u64 diag = s_diag[slot][lane];
+        u64 curb = cur;
+        int lastact = -1;
+        if (cur != ~0ull) {
+            u64 m = uniform64(__ballot(diag != 0ull));
+            while (m) {
+                const int r = __builtin_ctzll(m);
+                m &= m - 1;
+                if (!((cur >> r) & 1ull)) { curb = cur; lastact = r; cur |= readlane64(diag, r); }
+            }
+        }
+        const u64 kept = ~cur;
+        const int nk = __builtin_popcountll(kept);
+        const int rl = nk ? 63 - __builtin_clzll(kept) : 0;
+        const int len = s_len[slot];
+        if (tid == 0) s_new[slot] = 0;
+        if (nk) {
+            if (wave == 0 && ((kept >> lane) & 1ull))
+                keep[total + __builtin_popcountll(kept & ((1ull << lane) - 1ull))] = (int64_t)s_order[slot][lane];
+            // pass 1: every kept row but the last one
+            const u64 others = kept & ~(1ull << rl);
+            if (tid < len) {
+                const u32 k = s_key[slot][tid];
+                if ((others >> (k >> 16)) & 1ull) atomicOr((unsigned long long *)&remv[k & 0xffffu], (unsigned long long)s_val[slot][tid]);
+            }
+            if (len > CSR_LDS_ENTRIES) {                    // a long run: its tail straight from memory
+                const int o = s_boff[ib];
+                for (int e = CSR_LDS_ENTRIES + tid; e < len; e += 1024) {
+                    const u32 k = ekey[o + e];
+                    if ((others >> (k >> 16)) & 1ull) atomicOr((unsigned long long *)&remv[k & 0xffffu], (unsigned long long)eval[o + e]);
+                }
+            }
+        }
+        __syncthreads();
+        if (nk) {
+            // pass 2: the last kept row, counting the bits it is the first to set (the numel()>1 quirk needs that)
+            int fresh = 0;
+            if (tid < len) {
+                const u32 k = s_key[slot][tid];
+                if ((int)(k >> 16) == rl) {
+                    const u64 v = s_val[slot][tid];
+                    const u64 old = atomicOr((unsigned long long *)&remv[k & 0xffffu], (unsigned long long)v);
+                    fresh = __builtin_popcountll(v & ~old);
+                }
+            }
+            if (len > CSR_LDS_ENTRIES) {
+                const int o = s_boff[ib];
+                for (int e = CSR_LDS_ENTRIES + tid; e < len; e += 1024) {
+                    const u32 k = ekey[o + e];
+                    if ((int)(k >> 16) == rl) {
+                        const u64 v = eval[o + e];
+                        const u64 old = atomicOr((unsigned long long *)&remv[k & 0xffffu], (unsigned long long)v);
+                        fresh += __builtin_popcountll(v & ~old);
+                    }
+                }
+            }
+            if (__ballot(fresh != 0)) {
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) fresh += __shfl_xor(fresh, d, 64);
+                if (lane == 0) atomicAdd(&s_new[slot], fresh);
+            }
+        }
+        publish((jj + 1) % CSR_AHEAD, (ib + 1) & 1);            // block ib+1; (jj+1) % AHEAD == (ib+1) % AHEAD: ib0 is a multiple
+        fetch((jj + 1) % CSR_AHEAD, ib + 1 + CSR_AHEAD);
+        __syncthreads();
+        if (nk) {
+            any_kept = 1; last_r = rl; last_curb = (rl == lastact) ? curb : cur;
+            last_new = s_new[slot];
+            total += nk;
+        }
+      }
+    }
+    if (quirk && any_kept) {
+        // yolo.py:196 `while ids_sorted.numel()>1`: the last kept box is dropped iff nothing ranked below it was still
+        // alive before its own row was applied: no such bit in its own block, none set first by its row further right
+        const u64 above = (last_r == 63) ? 0ull : (~0ull << (last_r + 1));
+        if ((((~last_curb) & above) == 0ull) && last_new == 0) total -= 1;
+    }
+    if (tid == 0) keep_count[img] = total;
+}
+
 // ---------------------------------------------------------------- host
 extern "C" size_t dg_nms_workspace_bytes(int64_t batch, int64_t nmax)
 {
@@ -626,9 +931,26 @@ extern "C" int dg_nms_phase_reduce(const int32_t *counts, int64_t batch, int64_t
 #define RED(T, WPT) hipLaunchKernelGGL((k_nms_reduce<T, WPT>), dim3((unsigned)batch), dim3(T), 0, st, w.mask, w.order, counts, \
                                        nmax, w.Np, w.W, quirk_drop_last, keep, keep_count)
     if (w.W <= 64) RED(64, 1);
-    else if (w.W <= 1024)
+    else if (w.W <= 1024) {
+        // compact the mask, then the LDS-fed reduce; an image whose entries do not fit falls to the summary-driven kernel
+        hipLaunchKernelGGL(k_nms_csr_count, dim3((unsigned)(w.Np / 256 + (w.Np % 256 != 0)), (unsigned)batch), dim3(256), 0, st, w.rsum,
+                           counts, nmax, w.Np, w.W, w.SW, w.bcnt);
+        hipLaunchKernelGGL(k_nms_csr_scan, dim3((unsigned)batch), dim3(1024), 0, st, w.bcnt, counts, nmax, w.W, w.ecap, w.boff, w.cursor,
+                           w.cflag);
+        if ((w.SW & (w.SW - 1)) == 0 && w.SW <= 64) {
+            int sh = 0;
+            while ((1ll << sh) < w.SW) ++sh;
+            hipLaunchKernelGGL(k_nms_csr_fill_wave, dim3((unsigned)dg_cdiv(w.Np * w.SW, 256), (unsigned)batch), dim3(256), 0, st, w.mask,
+                               w.rsum, counts, nmax, w.Np, w.W, w.SW, sh, w.ecap, w.cflag, w.cursor, w.ekey, w.eval);
+        } else {
+            hipLaunchKernelGGL(k_nms_csr_fill, dim3((unsigned)dg_cdiv(w.Np * w.SW, 256), (unsigned)batch), dim3(256), 0, st, w.mask, w.rsum,
+                               counts, nmax, w.Np, w.W, w.SW, w.ecap, w.cflag, w.cursor, w.ekey, w.eval);
+        }
+        hipLaunchKernelGGL(k_nms_reduce_csr, dim3((unsigned)batch), dim3(1024), 0, st, w.mask, w.order, counts, nmax, w.Np, w.W, w.ecap,
+                           w.cflag, w.boff, w.ekey, w.eval, quirk_drop_last, keep, keep_count);
         hipLaunchKernelGGL((k_nms_reduce_sum<1024>), dim3((unsigned)batch), dim3(1024), (size_t)w.W * 16, st, w.mask, w.rsum, w.order,
-                           counts, nmax, w.Np, w.W, w.SW, quirk_drop_last, keep, keep_count);
+                           counts, nmax, w.Np, w.W, w.SW, quirk_drop_last, keep, keep_count, w.cflag);
+    }
     else if (w.W <= 4096) RED(1024, 4);
     else RED(1024, 16);
 #undef RED
