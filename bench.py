@@ -301,6 +301,15 @@ def main():
     gout_alias = w.gout_alias
     del w
     torch.cuda.empty_cache()
+    # what a plain device-to-device copy reaches on this box (read + write bytes), as SURVEY 8(d) asks: the second yardstick
+    src = torch.empty(1 << 30, dtype=torch.float32, device=d.dev)
+    dst = torch.empty_like(src)
+    t_copy = ev_time(lambda: dst.copy_(src), 5, 2)
+    copy_gbps = 2 * src.numel() * 4 / (t_copy * 1e-3) / 1e9
+    del src, dst
+    torch.cuda.empty_cache()
+    roofline["d2d_copy_GBps"] = copy_gbps
+    roofline["frac_of_d2d_copy"] = achieved / copy_gbps
 
     extra = {"phases_ms_rank0": phases, "grad_out_aliases_out": gout_alias}
     if not a.no_extras:

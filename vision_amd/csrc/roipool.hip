@@ -199,6 +199,9 @@ __device__ __forceinline__ void roi_task_staged(char *smem, const char *__restri
             if (NANSAFE) oidx[ph * RP + i] = ibase + (code[i] >> 3) * W + min(ws[i] + (code[i] & 7), we[i] - 1);
             else oidx[ph * RP + i] = ibase + ws[i] + code[i];
         }
+        // every ring read of this strip has returned before the next strip may issue LDS-DMA over these rows (issue
+        // order alone does not keep a DMA write behind a queued ds_read; see roi_task_exact)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         STAMP(t5);
         STAMP_ADD(2, t3, t4); STAMP_ADD(3, t4, t5);
     }
