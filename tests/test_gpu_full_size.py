@@ -1,0 +1,142 @@
+"""Parity at BASELINE.json's full sizes through size-independent properties (the oracle takes minutes to hours there).
+Every check goes through the product path (C ABI); torch on the GPU is only the checker."""
+import numpy as np
+import pytest
+import torch
+
+from vision_amd import workloads as wl
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def va():
+    from vision_amd import _abi
+    _abi.load()
+    return _abi
+
+
+@pytest.mark.parametrize("dense,thr", [(False, 0.5), (False, 0.7), (True, 0.5), (True, 0.7)])
+def test_nms_64k_properties(va, dense, thr):
+    """config 5: keep list sorted by score; no kept pair reaches thr; every dropped box is covered by a kept box that
+    outranks it (so the list is the greedy one: the greedy solution is unique given the order); NMS of the kept set
+    keeps all of it (idempotence; the quirk can only take the last one)."""
+    from vision_amd import ops
+    b, s = wl.stress_boxes(0, 65536, dense=dense)
+    bt, st = torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()
+    keep, cnt = ops.nms_batched(bt[None], st[None], None, thr, False)
+    k = keep[0, :int(cnt[0])]
+    assert k.numel() > 0 and k.unique().numel() == k.numel()
+    ks = st[k]
+    assert bool((ks[1:] < ks[:-1]).all())                                  # descending (scores are tie-free)
+    kb = bt[k]
+    thr32 = torch.tensor(thr, dtype=torch.float32).item()
+    # kept x kept, in row chunks
+    rank = torch.empty(65536, dtype=torch.int64, device="cuda"); rank[torch.argsort(st, descending=True)] = torch.arange(65536, device="cuda")
+    covered = torch.zeros(65536, dtype=torch.bool, device="cuda")
+    for lo in range(0, k.numel(), 4096):
+        iou = ops.iou_pairwise(kb[lo:lo + 4096], kb)                       # rows: kept chunk, cols: all kept
+        idx = torch.arange(lo, min(lo + 4096, k.numel()), device="cuda")
+        iou[torch.arange(idx.numel(), device="cuda"), idx] = 0.0
+        assert bool((iou < thr32).all()), "two kept boxes overlap at or above the threshold"
+        alli = ops.iou_pairwise(kb[lo:lo + 4096], bt)                      # rows: kept chunk, cols: every box
+        hit = (~(alli < thr32)) & (rank[k[lo:lo + 4096]][:, None] < rank[None, :])
+        covered |= hit.any(0)
+    dropped = torch.ones(65536, dtype=torch.bool, device="cuda"); dropped[k] = False
+    assert bool(covered[dropped].all()), "a dropped box is not suppressed by any higher-ranked kept box"
+    keep2, cnt2 = ops.nms_batched(kb[None], ks[None], None, thr, False)
+    assert int(cnt2[0]) == k.numel() and bool((keep2[0, :k.numel()] == torch.arange(k.numel(), device="cuda")).all())
+    # the reference's numel()>1 rule drops at most the last kept box and nothing else
+    keepq, cntq = ops.nms_batched(bt[None], st[None], None, thr, True)
+    kq = keepq[0, :int(cntq[0])]
+    assert int(cntq[0]) in (k.numel(), k.numel() - 1) and bool((kq == k[:kq.numel()]).all())
+
+
+def test_pairwise_64k_properties(va):
+    """config 5: the 64k x 64k matrix is symmetric bit for bit, its diagonal is a/(a+eps), entries are in [0,1]."""
+    from vision_amd import ops
+    b, _ = wl.stress_boxes(0, 65536, dense=True)
+    bt = torch.from_numpy(b).cuda()
+    m = ops.iou_pairwise(bt, bt)
+    assert m.shape == (65536, 65536)
+    for lo in range(0, 65536, 8192):
+        blk = m[lo:lo + 8192]
+        assert bool((blk >= 0).all()) and bool((blk <= 1).all())
+        assert bool((blk == m[:, lo:lo + 8192].T).all())
+    area = ((bt[:, 2] - bt[:, 0]) * (bt[:, 3] - bt[:, 1])).abs()
+    assert bool((m.diagonal() == area / (((area + area) - area) + 1e-7)).all())
+
+
+def test_roipool_batch_properties(va):
+    """config 3 shape at 64 images x 2000 RoIs: each pooled value is the map value at its argmax, the argmax lies in
+    its bin, nothing in the bin is larger; the backward conserves the gradient mass per (image, channel) and is linear."""
+    from vision_amd import ops
+    images = 64
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(1)
+    img = torch.randn((images, 512, 38, 50), device=dev)
+    rois = torch.from_numpy(np.concatenate([wl.frcnn_rois(i) for i in range(images)])).to(dev)
+    idx = torch.arange(images, device=dev).repeat_interleave(2000)
+    win, st = ops.roi_windows(rois, idx, images, 38, 50, dev)
+    assert int(st.item()) == 0
+    out, arg = ops.roipool_forward(img, win, "max")
+    n = win.shape[0]
+    for lo in range(0, n, 16000):
+        hi = min(n, lo + 16000)
+        w_ = win[lo:hi].long()
+        a = arg[lo:hi].long()
+        planes = img[w_[:, 4]]                                              # (m,512,38,50) view by gather would be huge: index flat
+        flat = img.view(images, 512, -1)
+        got = torch.gather(flat[w_[:, 4]], 2, a.view(hi - lo, 512, 49)).view(hi - lo, 512, 7, 7)
+        del planes
+        assert bool((got == out[lo:hi]).all())
+        ay, ax = a // 50, a % 50
+        i7 = torch.arange(7, device=dev)
+        Lh, Lw = (w_[:, 3] - w_[:, 1])[:, None], (w_[:, 2] - w_[:, 0])[:, None]
+        hs = w_[:, 1:2] + (i7[None] * Lh) // 7; he = w_[:, 1:2] + ((i7[None] + 1) * Lh + 6) // 7
+        ws = w_[:, 0:1] + (i7[None] * Lw) // 7; we = w_[:, 0:1] + ((i7[None] + 1) * Lw + 6) // 7
+        assert bool(((ay >= hs[:, None, :, None]) & (ay < he[:, None, :, None]) & (ax >= ws[:, None, None, :]) & (ax < we[:, None, None, :])).all())
+    # bin maximum against torch's own adaptive max pool on a sample of RoIs
+    for r in (0, 777, 64001, n - 1):
+        x1, y1, x2, y2, b = [int(v) for v in win[r]]
+        ref = torch.nn.functional.adaptive_max_pool2d(img[b:b + 1, :, y1:y2, x1:x2], 7)[0]
+        assert bool((ref == out[r]).all())
+    g1 = torch.randn_like(out); g2 = torch.randn_like(out)
+    gi1 = ops.roipool_backward(g1, arg, win, img.shape, "max").clone()
+    gi2 = ops.roipool_backward(g2, arg, win, img.shape, "max").clone()
+    g12 = g1 + 2.0 * g2
+    gi12 = ops.roipool_backward(g12, arg, win, img.shape, "max")
+    torch.testing.assert_close(gi12, gi1 + 2.0 * gi2, rtol=1e-4, atol=1e-3)       # fp32 sums of ~100 terms, different order
+    mass_out = torch.zeros((images, 512), device=dev, dtype=torch.float64)
+    mass_out.index_add_(0, idx, g1.double().sum((2, 3)))
+    torch.testing.assert_close(gi1.double().sum((2, 3)), mass_out, rtol=1e-5, atol=1e-2)
+
+
+def test_kmeans_10m_properties(va):
+    """config 4: one Lloyd step on 10 M boxes -- labels equal torch's fp32 argmin of the same formula (same op order,
+    first minimum wins), counts add up to N, the fixed-point sums equal an exact integer re-summation."""
+    from vision_amd import ops
+    wh_np = wl.anchor_wh(0, 10_000_000)
+    wh = torch.from_numpy(wh_np).cuda()
+    cent = wh[torch.tensor([5, 77, 1234, 99999, 5000000], device="cuda")].clone()
+    labels = torch.full((wh.shape[0],), 255, dtype=torch.uint8, device="cuda")
+    acc = torch.zeros(17, dtype=torch.int64, device="cuda")
+    ops.kmeans_step(wh, cent, labels, acc)
+    w, h = wh[:, 0:1], wh[:, 1:2]
+    inter = torch.minimum(w, cent[None, :, 0]) * torch.minimum(h, cent[None, :, 1])
+    uni = ((w * h) + (cent[None, :, 0] * cent[None, :, 1])) - inter
+    d = 1.0 - inter / uni
+    want = d.argmin(1)
+    # argmin's tie order is not promised by torch: compare through the distance of the chosen centroid and the index rule
+    dl = d.gather(1, labels.long()[:, None])[:, 0]
+    assert bool((dl == d.min(1).values).all())
+    first = (d == d.min(1, keepdim=True).values).float().argmax(1)
+    assert bool((labels.long() == first).all())
+    del want
+    a = acc.cpu().numpy()
+    assert a[10:15].sum() == wh.shape[0] and a[15] == wh.shape[0]             # counts, changed (all labels were 255)
+    fx = torch.round(wh.double() * 4294967296.0).long()
+    for c in range(5):
+        sel = labels == c
+        assert int(fx[sel, 0].sum()) == a[c] and int(fx[sel, 1].sum()) == a[5 + c] and int(sel.sum()) == a[10 + c]
+    assert int(torch.round(dl.double() * 4294967296.0).long().sum()) == a[16]
