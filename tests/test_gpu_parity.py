@@ -274,6 +274,33 @@ def test_roipool_every_crop_width_with_ties(va, oracle, with_nan):
     assert np.array_equal(arg.cpu().numpy(), warg)
 
 
+def test_roipool_avg_every_crop_width(va, oracle):
+    """avg mode (the reference class as written, fast_rcnn.py:354): every crop width 1..50 -- the width-specialised
+    staged path up to 24, the direct path beyond -- against the oracle and against torch's AdaptiveAvgPool2d."""
+    from vision_amd import ops
+    rng = np.random.default_rng(23)
+    B, C, H, W = 2, 128, 38, 50
+    img = rng.standard_normal((B, C, H, W), dtype=np.float32)
+    wins = []
+    for lw in range(1, W + 1):
+        for lh in sorted(set(int(v) for v in rng.integers(1, H + 1, 4)) | {1 + lw % 7, H if lw % 9 == 0 else 7}):
+            x1 = int(rng.integers(0, W - lw + 1)); y1 = int(rng.integers(0, H - lh + 1))
+            wins.append((x1, y1, x1 + lw, y1 + lh))
+    wins = np.array(wins, np.int64)
+    rois = np.stack([(wins[:, 0] + 0.25) / W, (wins[:, 1] + 0.25) / H, (wins[:, 2] - 0.25) / W, (wins[:, 3] - 0.25) / H], 1)
+    idx = rng.integers(0, B, len(wins)).astype(np.int64)
+    x = torch.from_numpy(img).cuda()
+    win, status = ops.roi_windows(rois, idx, B, H, W, x.device)
+    out, arg = ops.roipool_forward(x, win, "avg")
+    assert arg is None
+    want, _ = oracle.roipool_fwd(img, rois, idx, 7, "avg")
+    np.testing.assert_allclose(out.cpu().numpy(), want, rtol=1e-6, atol=1e-6)          # fp32 sums in a different order
+    for r in range(0, len(wins), 17):
+        x1, y1, x2, y2 = wins[r]
+        ref = torch.nn.functional.adaptive_avg_pool2d(x[idx[r]:idx[r] + 1, :, y1:y2, x1:x2], 7)[0]
+        torch.testing.assert_close(out[r], ref, rtol=1e-6, atol=1e-6)
+
+
 def test_roipool_odd_channels_and_batch(va, oracle):
     from vision_amd import ops
     rng = np.random.default_rng(2)

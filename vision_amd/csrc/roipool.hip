@@ -312,6 +312,71 @@ __device__ __forceinline__ void roi_task_exact(char *smem, const char *__restric
     }
 }
 
+// Staged task for avg mode (the reference class as written: AdaptiveAvgPool2d, rcnn/fast_rcnn.py:354), specialised
+// on the crop width like roi_task_exact: same LDS-DMA row ring, per (row, bin) the sum of the bin's pixels, bin sums
+// accumulated over the strip's rows, result = sum / rows / columns (the direct path's order).
+template <int LW>
+__device__ __forceinline__ void roi_task_avg(char *smem, const char *__restrict__ imgc0, int pixbytes, int W, int lane,
+                                             int x1, int y1, int y2, int R, float (&oval)[RBINS])
+{
+    constexpr int Lwp = (LW + 3) & ~3, NQ = Lwp >> 2, rowbytes = Lwp * 256;
+    const int Lh = y2 - y1;
+    const int pxl = lane >> 4;
+    unsigned voff[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) voff[q] = (unsigned)(min(4 * q + pxl, LW - 1) * pixbytes + (lane & 15) * 16);
+    int loaded = y1, lslot = 0;
+    auto issue_rows = [&](int ylimit) {
+        while (loaded < ylimit) {
+            const char *rowg = imgc0 + (int64_t)(loaded * W + x1) * pixbytes;      // uniform
+            char *rowl = smem + lslot * rowbytes;
+#pragma unroll
+            for (int q = 0; q < NQ; ++q)
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(rowg + voff[q]),
+                                                 (__attribute__((address_space(3))) void *)(rowl + q * 1024), 16, 0, 0);
+            lslot = (lslot + 1 == R) ? 0 : lslot + 1;
+            ++loaded;
+        }
+    };
+    issue_rows(min(y2, y1 + R));
+    const char *lbase = smem + lane * 4;
+    int slot = 0, prev_hs = y1;
+#pragma unroll
+    for (int ph = 0; ph < RP; ++ph) {
+        const int hs = y1 + (ph * Lh) / RP, he = y1 + ((ph + 1) * Lh + RP - 1) / RP;
+        issue_rows(he);                                    // normally already issued
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // rows < he have landed
+        issue_rows(min(y2, hs + R));                       // prefetch; only overwrites rows < hs
+        slot += hs - prev_hs;
+        if (slot >= R) slot -= R;
+        prev_hs = hs;
+        float acc[RP];
+#pragma unroll
+        for (int i = 0; i < RP; ++i) acc[i] = 0.f;
+        int sl = slot, so = slot * rowbytes;
+        for (int r = 0; r < he - hs; ++r) {
+            const char *rowp = lbase + so;
+#pragma unroll
+            for (int i = 0; i < RP; ++i) {
+                const int s = (i * LW) / RP, w = ((i + 1) * LW + RP - 1) / RP - s;      // folded: i and LW are constants
+                float rs = *(const float *)(rowp + s * 256);
+#pragma unroll
+                for (int j = 1; j < w; ++j) rs += *(const float *)(rowp + (s + j) * 256);
+                acc[i] += rs;
+            }
+            so += rowbytes;
+            if (++sl == R) { sl = 0; so = 0; }
+        }
+        const float rows = (float)(he - hs);
+#pragma unroll
+        for (int i = 0; i < RP; ++i) {
+            const int s = (i * LW) / RP, w = ((i + 1) * LW + RP - 1) / RP - s;
+            oval[ph * RP + i] = acc[i] / rows / (float)w;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // ring reads returned before the next strip's DMA (see roi_task_exact)
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_roipool_fwd(const float *__restrict__ nhwc, int C, int H, int W,
                                                     const int32_t *__restrict__ win, int cblocks, int64_t ntasks,
@@ -456,8 +521,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 emit();
             }
         }
+        if (MODE == DG_POOL_AVG) {
+            const int Lwp = (Lw + 3) & ~3;
+            const int R = RING_PX / Lwp;
+            const int qh = Lh / RP, rh = Lh - qh * RP;
+            const int maxrows = qh + (rh > 1 ? 2 : rh);
+            staged = (R >= maxrows) && (Lw <= 24) && (cvalid == 64) && ((C & 3) == 0) && ((((uintptr_t)nhwc) & 15) == 0) &&
+                     ((int64_t)H * W * C * 4 < (1ll << 31));
+            if (staged) {
+                float oval[RBINS];
+                char *smem = reinterpret_cast<char *>(smemf);
+                const char *imgc0 = reinterpret_cast<const char *>(nhwc + ((int64_t)b * H * W) * C + c0);
+#define AVGW(LWV) case LWV: roi_task_avg<LWV>(smem, imgc0, C * 4, W, lane, x1, y1, y2, R, oval); break
+                switch (Lw) {
+                AVGW(1); AVGW(2); AVGW(3); AVGW(4); AVGW(5); AVGW(6); AVGW(7); AVGW(8); AVGW(9); AVGW(10); AVGW(11); AVGW(12);
+                AVGW(13); AVGW(14); AVGW(15); AVGW(16); AVGW(17); AVGW(18); AVGW(19); AVGW(20); AVGW(21); AVGW(22); AVGW(23);
+                default: roi_task_avg<24>(smem, imgc0, C * 4, W, lane, x1, y1, y2, R, oval); break;
+                }
+#undef AVGW
+#pragma unroll
+                for (int i = 0; i < RBINS; ++i) sval[lane * RBINS + i] = oval[i];
+                emit();
+            }
+        }
         if (!staged) {
-            // ---- direct path (any crop size, partial channel blocks, avg mode): reads the map from L2/HBM per bin
+            // ---- direct path (any crop size, partial channel blocks): reads the map from L2/HBM per bin
             const int c = c0 + (lane < cvalid ? lane : cvalid - 1);
             const float *base = nhwc + (int64_t)b * H * W * C + c;
 #pragma unroll 1
