@@ -671,11 +671,31 @@ __device__ __forceinline__ void lds_fadd(float *p, float g)
     }
 }
 
+// four accumulates at p, p+stride, p+2*stride, p+3*stride with their reads and compare-and-swaps issued together
+__device__ __forceinline__ void lds_fadd4(float *p, int stride, const float (&g)[4])
+{
+    int *ip = reinterpret_cast<int *>(p);
+    int old[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) old[c] = *reinterpret_cast<volatile int *>(ip + c * stride);
+    bool done[4] = {false, false, false, false};
+    while (true) {
+        int got[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            got[c] = done[c] ? old[c] : atomicCAS(ip + c * stride, old[c], __float_as_int(__int_as_float(old[c]) + g[c]));
+        bool all = true;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { done[c] = done[c] || (got[c] == old[c]); old[c] = got[c]; all = all && done[c]; }
+        if (all) break;
+    }
+}
+
 // grid: x = channel block (CB channels), y = image.  Dynamic LDS: CB*H*W floats.
 // VEC: CB*49 % 4 == 0 and 16-byte aligned tensors -> each thread moves 4 consecutive elements of one RoI
 // (16-byte loads of grad_out and argmax), two such groups in flight per thread.
-template <int MODE, bool VEC>
-__global__ __launch_bounds__(256) void k_roipool_bwd(const float *__restrict__ grad_out, const int32_t *__restrict__ argmax,
+template <int MODE, bool VEC, int NT>
+__global__ __launch_bounds__(NT) void k_roipool_bwd(const float *__restrict__ grad_out, const int32_t *__restrict__ argmax,
                                                      const int32_t *__restrict__ win, const int32_t *__restrict__ off,
                                                      const int32_t *__restrict__ list, int C, int H, int W, int CB,
                                                      float *__restrict__ grad_in)
@@ -685,7 +705,7 @@ __global__ __launch_bounds__(256) void k_roipool_bwd(const float *__restrict__ g
     const int b = blockIdx.y, c0 = blockIdx.x * CB;
     const int cb = (C - c0) < CB ? (C - c0) : CB;
     const int HW = H * W;
-    for (int i = tid; i < cb * HW; i += 256) plane[i] = 0.f;
+    for (int i = tid; i < cb * HW; i += NT) plane[i] = 0.f;
     __syncthreads();
     // gridDim.z > 1 (few images): the image's RoI list is split over z, every part adds its LDS slice into a
     // pre-zeroed grad_in with global float atomics (contiguous 256-byte wave accesses)
@@ -697,8 +717,8 @@ __global__ __launch_bounds__(256) void k_roipool_bwd(const float *__restrict__ g
         const int per4 = per >> 2;                   // float4 groups per RoI
         const int64_t work = (int64_t)(r1 - r0) * per4;
         int64_t t = tid;
-        for (; t + 256 < work; t += 512) {           // two independent 16-byte pairs in flight
-            const int64_t t2 = t + 256;
+        for (; t + NT < work; t += 2 * NT) {           // two independent 16-byte pairs in flight
+            const int64_t t2 = t + NT;
             const int ra = (int)(t / per4), qa = (int)(t - (int64_t)ra * per4);
             const int rb = (int)(t2 / per4), qb = (int)(t2 - (int64_t)rb * per4);
             const int64_t oa = ((int64_t)list[r0 + ra] * C + c0) * RBINS + 4 * qa;
@@ -717,7 +737,7 @@ __global__ __launch_bounds__(256) void k_roipool_bwd(const float *__restrict__ g
             lds_fadd(&plane[((eb + 2) / RBINS) * HW + ib.z], gb.z);
             lds_fadd(&plane[((eb + 3) / RBINS) * HW + ib.w], gb.w);
         }
-        for (; t < work; t += 256) {
+        for (; t < work; t += NT) {
             const int ra = (int)(t / per4), qa = (int)(t - (int64_t)ra * per4);
             const int64_t oa = ((int64_t)list[r0 + ra] * C + c0) * RBINS + 4 * qa;
             const float4 ga = *reinterpret_cast<const float4 *>(grad_out + oa);
@@ -728,34 +748,109 @@ __global__ __launch_bounds__(256) void k_roipool_bwd(const float *__restrict__ g
             lds_fadd(&plane[((ea + 2) / RBINS) * HW + ia.z], ga.z);
             lds_fadd(&plane[((ea + 3) / RBINS) * HW + ia.w], ga.w);
         }
+    } else if (MODE == DG_POOL_AVG) {
+        // avg mode, one wave per RoI (all channels of the slice).  The bin gradients become per-pixel shares
+        // g/rows/cols in a per-wave LDS scratch, the bins covering each crop row / column come from a small table
+        // (one integer division per row and column, not per pixel), and the lanes then walk the crop in 8x8 tiles:
+        // each pixel sums the shares of the bins that contain it (1..2 per axis, more for crops under 7) and is added
+        // ONCE to the LDS plane.  The scatter form (every bin looping over its pixels) costs several times as many LDS
+        // read-modify-writes.  The window of the next RoI is fetched while the current one is processed.
+        __shared__ float share[NT / 64][16 * 64];                 // [wave][channel (<= 16)][bin]
+        __shared__ unsigned char binlo[NT / 64][2][64], binhi[NT / 64][2][64];   // [wave][axis][coordinate]
+        const int lane = tid & 63, wave = tid >> 6;
+        const int ly = lane >> 3, lx = lane & 7;
+        // software pipeline over the wave's RoIs: the RoI index is fetched two ahead, window and bin gradients one ahead
+        const int nr = r1 - r0;
+        int rr = wave;
+        int roi1 = (rr < nr) ? list[r0 + rr] : 0;                       // current
+        int roi2 = (rr + NT / 64 < nr) ? list[r0 + rr + NT / 64] : 0;               // next
+        int4 wn = make_int4(0, 0, 1, 1);
+        float gn[4] = {0.f, 0.f, 0.f, 0.f};
+        auto fetch_roi = [&](int roi) {
+            const int32_t *w = win + 5 * (int64_t)roi;
+            wn = make_int4(w[0], w[1], w[2], w[3]);
+            if (lane < RBINS) {
+                const float *g = grad_out + ((int64_t)roi * C + c0) * RBINS + lane;
+#pragma unroll
+                for (int ch = 0; ch < 4; ++ch) gn[ch] = (ch < cb) ? g[ch * RBINS] : 0.f;
+            }
+        };
+        if (rr < nr) fetch_roi(roi1);
+        for (; rr < nr; rr += NT / 64) {
+            const int roi = __builtin_amdgcn_readfirstlane(roi1);
+            const int x1 = __builtin_amdgcn_readfirstlane(wn.x), y1 = __builtin_amdgcn_readfirstlane(wn.y);
+            const int Lw = __builtin_amdgcn_readfirstlane(wn.z) - x1, Lh = __builtin_amdgcn_readfirstlane(wn.w) - y1;
+            float gc[4];
+#pragma unroll
+            for (int ch = 0; ch < 4; ++ch) gc[ch] = gn[ch];
+            roi1 = roi2;
+            if (rr + NT / 64 < nr) fetch_roi(roi1);
+            roi2 = (rr + 2 * (NT / 64) < nr) ? list[r0 + rr + 2 * (NT / 64)] : 0;
+            const bool small = Lh <= 64 && Lw <= 64;
+            if (small) {
+                // bins whose range [floor(i*L/7), ceil((i+1)*L/7)) contains coordinate `lane`
+                if (lane < Lh) { binlo[wave][0][lane] = (unsigned char)((lane * RP) / Lh); binhi[wave][0][lane] = (unsigned char)(((lane + 1) * RP + Lh - 1) / Lh - 1); }
+                if (lane < Lw) { binlo[wave][1][lane] = (unsigned char)((lane * RP) / Lw); binhi[wave][1][lane] = (unsigned char)(((lane + 1) * RP + Lw - 1) / Lw - 1); }
+            }
+            if (lane < RBINS) {
+                const int ph = lane / RP, pw = lane - ph * RP;
+                const float kh = (float)(((ph + 1) * Lh + RP - 1) / RP - (ph * Lh) / RP), kw = (float)(((pw + 1) * Lw + RP - 1) / RP - (pw * Lw) / RP);
+                if (cb <= 4) {
+#pragma unroll
+                    for (int ch = 0; ch < 4; ++ch) share[wave][ch * 64 + lane] = gc[ch] / kh / kw;
+                } else {
+                    const float *g = grad_out + ((int64_t)roi * C + c0) * RBINS + lane;
+                    for (int ch = 0; ch < cb; ++ch) share[wave][ch * 64 + lane] = g[ch * RBINS] / kh / kw;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            float *pl = plane + y1 * W + x1;
+            for (int ty = 0; ty < Lh; ty += 8) {
+                for (int tx = 0; tx < Lw; tx += 8) {
+                    const int ry = ty + ly, rx = tx + lx;
+                    if (ry < Lh && rx < Lw) {
+                        int ph0, ph1, pw0, pw1;
+                        if (small) { ph0 = binlo[wave][0][ry]; ph1 = binhi[wave][0][ry]; pw0 = binlo[wave][1][rx]; pw1 = binhi[wave][1][rx]; }
+                        else { ph0 = (ry * RP) / Lh; ph1 = ((ry + 1) * RP + Lh - 1) / Lh - 1; pw0 = (rx * RP) / Lw; pw1 = ((rx + 1) * RP + Lw - 1) / Lw - 1; }
+                        if (cb == 4) {                       // the usual slice: four independent chains in flight
+                            float sum[4] = {0.f, 0.f, 0.f, 0.f};
+                            for (int ph = ph0; ph <= ph1; ++ph)
+                                for (int pw = pw0; pw <= pw1; ++pw) {
+                                    const float *sp = &share[wave][ph * RP + pw];
+#pragma unroll
+                                    for (int ch = 0; ch < 4; ++ch) sum[ch] += sp[ch * 64];
+                                }
+                            lds_fadd4(&pl[ry * W + rx], HW, sum);
+                        } else {
+                            for (int ch = 0; ch < cb; ++ch) {
+                                float sum = 0.f;
+                                for (int ph = ph0; ph <= ph1; ++ph)
+                                    for (int pw = pw0; pw <= pw1; ++pw) sum += share[wave][ch * 64 + ph * RP + pw];
+                                lds_fadd(&pl[ch * HW + ry * W + rx], sum);
+                            }
+                        }
+                    }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();               // the scratch is rewritten for the next RoI
+        }
     } else {
         const int64_t work = (int64_t)(r1 - r0) * per;
-        for (int64_t t = tid; t < work; t += 256) {
+        for (int64_t t = tid; t < work; t += NT) {
             const int rr = (int)(t / per), e = (int)(t - (int64_t)rr * per);
             const int roi = list[r0 + rr];
             const int64_t o = ((int64_t)roi * C + c0) * RBINS + e;
-            const float g = grad_out[o];
-            const int ch = e / RBINS;
-            if (MODE == DG_POOL_MAX) {
-                lds_fadd(&plane[ch * HW + argmax[o]], g);
-            } else {
-                const int bin = e - ch * RBINS, ph = bin / RP, pw = bin - ph * RP;
-                const int32_t *w = win + 5 * (int64_t)roi;
-                const int x1 = w[0], y1 = w[1], Lw = w[2] - x1, Lh = w[3] - y1;
-                const int hs = y1 + (ph * Lh) / RP, he = y1 + ((ph + 1) * Lh + RP - 1) / RP;
-                const int ws = x1 + (pw * Lw) / RP, we = x1 + ((pw + 1) * Lw + RP - 1) / RP;
-                const float gd = g / (float)(he - hs) / (float)(we - ws);
-                for (int y = hs; y < he; ++y)
-                    for (int x = ws; x < we; ++x) lds_fadd(&plane[ch * HW + y * W + x], gd);
-            }
+            lds_fadd(&plane[(e / RBINS) * HW + argmax[o]], grad_out[o]);
         }
     }
     __syncthreads();
     float *gi = grad_in + ((int64_t)b * C + c0) * HW;
     if (gridDim.z == 1) {
-        for (int i = tid; i < cb * HW; i += 256) gi[i] = plane[i];
+        for (int i = tid; i < cb * HW; i += NT) gi[i] = plane[i];
     } else {
-        for (int i = tid; i < cb * HW; i += 256) atomicAdd(&gi[i], plane[i]);
+        for (int i = tid; i < cb * HW; i += NT) atomicAdd(&gi[i], plane[i]);
     }
 }
 
@@ -862,11 +957,11 @@ extern "C" int dg_roipool_bwd_f32(const float *grad_out, const int32_t *argmax, 
     const bool vec = mode == DG_POOL_MAX && CB % 4 == 0 && C % CB == 0 &&
                      ((((uintptr_t)grad_out) | ((uintptr_t)argmax)) & 15) == 0;
     if (mode == DG_POOL_MAX && vec)
-        hipLaunchKernelGGL((k_roipool_bwd<DG_POOL_MAX, true>), grid, dim3(256), lds, st, grad_out, argmax, win, w.off, w.list, (int)C, (int)H, (int)W, CB, grad_in);
+        hipLaunchKernelGGL((k_roipool_bwd<DG_POOL_MAX, true, 256>), grid, dim3(256), lds, st, grad_out, argmax, win, w.off, w.list, (int)C, (int)H, (int)W, CB, grad_in);
     else if (mode == DG_POOL_MAX)
-        hipLaunchKernelGGL((k_roipool_bwd<DG_POOL_MAX, false>), grid, dim3(256), lds, st, grad_out, argmax, win, w.off, w.list, (int)C, (int)H, (int)W, CB, grad_in);
+        hipLaunchKernelGGL((k_roipool_bwd<DG_POOL_MAX, false, 256>), grid, dim3(256), lds, st, grad_out, argmax, win, w.off, w.list, (int)C, (int)H, (int)W, CB, grad_in);
     else
-        hipLaunchKernelGGL((k_roipool_bwd<DG_POOL_AVG, false>), grid, dim3(256), lds, st, grad_out, argmax, win, w.off, w.list, (int)C, (int)H, (int)W, CB, grad_in);
+        hipLaunchKernelGGL((k_roipool_bwd<DG_POOL_AVG, false, 512>), grid, dim3(512), lds, st, grad_out, argmax, win, w.off, w.list, (int)C, (int)H, (int)W, CB, grad_in);
     DG_CHECK_LAUNCH("k_roipool_bwd");
     return DG_OK;
 }
