@@ -144,6 +144,24 @@ def test_nms_batched_ragged_vs_oracle(va, oracle):
             assert cnt[i] == len(want) and np.array_equal(keep[i, :cnt[i]], want), (i, quirk)
 
 
+def test_nms_batched_ragged_long_segments_vs_oracle(va, oracle):
+    """several images with more than 4096 boxes each and ragged counts: per-image offsets of the compact-mask reduce,
+    sparse and dense images side by side (a dense image falls back to the summary-driven reduce on its own)."""
+    from vision_amd import ops
+    N = 6000
+    counts = np.array([0, 1, 70, 4097, 6000, 5000], np.int32)
+    boxes = np.zeros((len(counts), N, 4), np.float32); scores = np.zeros((len(counts), N), np.float32)
+    for i in range(len(counts)):
+        b, s = wl.stress_boxes(100 + i, N, dense=(i == 5))
+        boxes[i], scores[i] = b, s
+    for thr, quirk in ((0.5, True), (0.3, False)):
+        keep, cnt = ops.nms_batched(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), torch.from_numpy(counts), thr, quirk)
+        keep, cnt = keep.cpu().numpy(), cnt.cpu().numpy()
+        for i in range(len(counts)):
+            want = oracle.nms(boxes[i, :counts[i]], scores[i, :counts[i]], thr, quirk)
+            assert cnt[i] == len(want) and np.array_equal(keep[i, :cnt[i]], want), (i, thr, quirk)
+
+
 def test_nms_frcnn_top(va, golden):
     from vision_amd import fast_rcnn
     t = golden("nms_frcnn_top")
