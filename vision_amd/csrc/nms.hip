@@ -16,6 +16,7 @@
 #include <math.h>
 
 #define SORT_CHUNK 4096  // elements sorted inside LDS (32 KiB of keys)
+#define NMS_CSR_MIN_W 8  // from 8 words (449 boxes) per image on, the reduce runs from the compact mask (k_nms_csr_*)
 
 struct NmsWs {
     int64_t Np, W, SW, Np2;
@@ -53,7 +54,7 @@ static NmsWs nms_layout(int64_t batch, int64_t nmax, void *base)
     w.order = (int32_t *)take((size_t)batch * w.Np * 4);
     w.mask = (u64 *)take((size_t)batch * w.Np * w.W * 8);
     w.rsum = (u64 *)take((size_t)batch * w.Np * w.SW * 8);
-    w.ecap = (w.W > 64 && w.W <= 1024) ? w.Np * 32 : 0;
+    w.ecap = (w.W >= NMS_CSR_MIN_W && w.W <= 1024) ? w.Np * 32 : 0;
     w.bcnt = (int32_t *)take((size_t)batch * w.W * 4);
     w.boff = (int32_t *)take((size_t)batch * (w.W + 1) * 4);
     w.cursor = (int32_t *)take((size_t)batch * w.W * 4);
@@ -930,7 +931,7 @@ extern "C" int dg_nms_phase_reduce(const int32_t *counts, int64_t batch, int64_t
     DG_REQUIRE(keep, "nms_reduce: null keep");
 #define RED(T, WPT) hipLaunchKernelGGL((k_nms_reduce<T, WPT>), dim3((unsigned)batch), dim3(T), 0, st, w.mask, w.order, counts, \
                                        nmax, w.Np, w.W, quirk_drop_last, keep, keep_count)
-    if (w.W <= 64) RED(64, 1);
+    if (w.W < NMS_CSR_MIN_W) RED(64, 1);
     else if (w.W <= 1024) {
         // compact the mask, then the LDS-fed reduce; an image whose entries do not fit falls to the summary-driven kernel
         hipLaunchKernelGGL(k_nms_csr_count, dim3((unsigned)(w.Np / 256 + (w.Np % 256 != 0)), (unsigned)batch), dim3(256), 0, st, w.rsum,
