@@ -26,15 +26,39 @@ class _HipBackend:
         self.labels = torch.full((self.wh.shape[0],), 255, dtype=torch.uint8, device=dev)
         self.acc = torch.zeros(3 * k + 2, dtype=torch.int64, device=dev)
         self.history = torch.zeros(max(iters, 1), dtype=torch.int64, device=dev)
+        self._bound = None
 
     def run_local(self, slot0, iters):
         ops.kmeans_run(self.wh, self.cent, self.labels, self.acc, self.history, slot0, iters)
 
+    # The sharded loop calls step / all-reduce / update once per iteration from Python: with the kernels at a few
+    # microseconds per shard the host side is the bottleneck, so the ABI calls are bound once with raw pointers.
+    def _bind(self):
+        lib = _abi.load()
+        dev = self.wh.device
+        n, k = self.wh.shape[0], self.cent.shape[0]
+        nbytes = lib.dg_kmeans_workspace_bytes(n, k)
+        self._ws = _abi.workspace(dev, nbytes)
+        st = _abi.stream_ptr(dev)
+        a = (_abi.ptr(self.wh), n, _abi.ptr(self.cent), k, _abi.ptr(self.labels), _abi.ptr(self.acc), _abi.ptr(self._ws), nbytes, st)
+        u = (_abi.ptr(self.acc), k, _abi.ptr(self.cent), _abi.ptr(self.history))
+        step_fn, upd_fn, check = lib.dg_kmeans_iou_step, lib.dg_kmeans_update, _abi.check
+        self._bound = (dev, st.value, lambda: check(step_fn(*a)), lambda slot: check(upd_fn(*u, slot, st)))
+
+    def _fast(self):
+        b = getattr(self, "_bound", None)
+        if b is None or b[0] != self.wh.device or b[1] != _abi.stream_ptr(self.wh.device).value:
+            self._bind()
+            b = self._bound
+        return b
+
     def step(self):
-        ops.kmeans_step(self.wh, self.cent, self.labels, self.acc)
+        with torch.cuda.device(self.wh.device):
+            self._fast()[2]()
 
     def update(self, slot):
-        ops.kmeans_update(self.acc, self.cent, self.history, slot)
+        with torch.cuda.device(self.wh.device):
+            self._fast()[3](slot)
 
     def history_host(self, upto):
         return self.history[:upto].cpu().numpy()
