@@ -270,7 +270,6 @@ __device__ __forceinline__ void roi_task_exact(char *smem, const char *__restric
             const char *rowp = lbase + so;
 #pragma unroll
             for (int i = 0; i < RP; ++i) {
-                constexpr int dummy = 0; (void)dummy;
                 const int s = (i * LW) / RP, w = ((i + 1) * LW + RP - 1) / RP - s;      // folded: i and LW are constants
                 float rm = *(const float *)(rowp + s * 256);
                 int j = 1;
