@@ -1,0 +1,76 @@
+"""Randomised differential test of every kernel family against the oracle: random shapes, seeds, thresholds,
+channel counts, NaN maps, ragged batches.  One-off (minutes of GPU time), complements tests/ with breadth."""
+import sys, time
+import numpy as np, torch
+sys.path.insert(0, ".")
+from vision_amd import ops, workloads as wl
+from oracle import oracle
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+rng = np.random.default_rng(2024)
+fail = []
+t0 = time.time()
+def chk(name, ok, info=""):
+    if not ok:
+        fail.append((name, info)); print("MISMATCH", name, info, flush=True)
+
+for it in range(rounds):
+    # ---- RoI pooling: random map size, channels, batch, windows incl. wide/tall, optional NaN
+    B = int(rng.integers(1, 4)); Cc = int(rng.choice([3, 64, 70, 128, 192])); H = int(rng.integers(8, 41)); W = int(rng.integers(8, 56))
+    img = rng.standard_normal((B, Cc, H, W), dtype=np.float32)
+    if rng.random() < 0.3: img = np.round(img * 2) / 2                      # ties
+    if rng.random() < 0.3: img[rng.random(img.shape) < 0.003] = np.nan
+    n = int(rng.integers(1, 300))
+    x1 = rng.integers(0, W, n); y1 = rng.integers(0, H, n)
+    x2 = np.minimum(W, x1 + rng.integers(1, W + 1, n)); y2 = np.minimum(H, y1 + rng.integers(1, H + 1, n))
+    rois = np.stack([(x1 + 0.3) / W, (y1 + 0.3) / H, (x2 - 0.3) / W, (y2 - 0.3) / H], 1)
+    idx = rng.integers(0, B, n).astype(np.int64)
+    x = torch.from_numpy(img).cuda()
+    win, st = ops.roi_windows(rois, idx, B, H, W, x.device)
+    for mode in ("max", "avg"):
+        out, arg = ops.roipool_forward(x, win, mode)
+        want, warg = oracle.roipool_fwd(img, rois, idx, 7, mode)
+        if mode == "max":
+            chk("roi fwd max", np.array_equal(out.cpu().numpy(), want, equal_nan=True) and np.array_equal(arg.cpu().numpy(), warg), (B, Cc, H, W, n))
+        else:
+            chk("roi fwd avg", np.allclose(out.cpu().numpy(), want, rtol=1e-5, atol=1e-5, equal_nan=True), (B, Cc, H, W, n))
+        if not np.isnan(img).any():
+            g = rng.standard_normal(want.shape, dtype=np.float32)
+            gin = ops.roipool_backward(torch.from_numpy(g).cuda(), arg, win, img.shape, mode).cpu().numpy()
+            wgin = oracle.roipool_bwd(g, warg, img.shape, rois, idx, 7, mode)
+            chk("roi bwd " + mode, np.allclose(gin, wgin, rtol=1e-4, atol=1e-3), (B, Cc, H, W, n))
+    # ---- NMS: ragged batch, random sizes crossing the kernel-selection boundaries, random threshold
+    nb = int(rng.integers(1, 5)); N = int(rng.choice([5, 98, 447, 449, 700, 2000, 4100, 9000]))
+    counts = rng.integers(0, N + 1, nb).astype(np.int32); counts[0] = N
+    boxes = np.zeros((nb, N, 4), np.float32); scores = np.zeros((nb, N), np.float32)
+    for i in range(nb):
+        b, s = wl.stress_boxes(int(rng.integers(1 << 30)), N, dense=bool(rng.integers(2)))
+        boxes[i], scores[i] = b, s
+    thr = float(rng.choice([0.05, 0.3, 0.5, 0.7, 0.95])); quirk = bool(rng.integers(2))
+    keep, cnt = ops.nms_batched(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), torch.from_numpy(counts), thr, quirk)
+    keep, cnt = keep.cpu().numpy(), cnt.cpu().numpy()
+    for i in range(nb):
+        wantk = oracle.nms(boxes[i, :counts[i]], scores[i, :counts[i]], thr, quirk)
+        chk("nms", cnt[i] == len(wantk) and np.array_equal(keep[i, :cnt[i]], wantk), (N, int(counts[i]), thr, quirk))
+    # ---- IoU pairwise / elementwise
+    a = wl.random_boxes(int(rng.integers(1 << 30)), int(rng.integers(1, 400))); b = wl.random_boxes(int(rng.integers(1 << 30)), int(rng.integers(1, 3000)))
+    chk("pairwise", np.array_equal(ops.iou_pairwise(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()).cpu().numpy(), oracle.iou_pairwise(a, b)))
+    # ---- k-means step: random n, k, unaligned shard start
+    k = int(rng.integers(1, 17)); nk = int(rng.integers(1, 300000)); off = int(rng.integers(0, 3))
+    wh = wl.anchor_wh(int(rng.integers(1 << 30)), nk + off)
+    cent = wh[rng.choice(nk, k, replace=(nk < k))].copy()
+    lab = rng.integers(0, k, nk).astype(np.uint8); lab0 = lab.copy()
+    acc = oracle.kmeans_step(wh[off:], cent, lab)
+    whd = torch.from_numpy(wh).cuda()[off:]
+    l2 = torch.from_numpy(lab0).cuda(); a2 = torch.zeros(3 * k + 2, dtype=torch.int64, device="cuda")
+    ops.kmeans_step(whd, torch.from_numpy(cent).cuda(), l2, a2)
+    chk("kmeans", np.array_equal(a2.cpu().numpy(), acc) and np.array_equal(l2.cpu().numpy(), lab), (nk, k, off))
+    # ---- YOLOv1 decode + loss
+    bs = int(rng.integers(1, 40)); Cn = int(rng.choice([1, 5, 20]))
+    out, tgt = wl.yolo1_batch(int(rng.integers(1 << 30)), bs, Cn)
+    ol, ocomp, ograd = oracle.yolo1_loss(out, tgt, quirk=True)
+    loss6, grad = ops.yolo1_loss(torch.from_numpy(out).cuda(), torch.from_numpy(tgt).cuda(), True)
+    chk("loss", abs(loss6[0].item() - ol) <= 3e-7 * abs(ol) and np.allclose(grad.cpu().numpy(), ograd, rtol=3e-6, atol=1e-7), (bs, Cn))
+    print(f"round {it}: failures {len(fail)}  ({time.time() - t0:.0f} s)", flush=True)
+print("TOTAL FAILURES", len(fail), fail[:10])
+sys.exit(1 if fail else 0)

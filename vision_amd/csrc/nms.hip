@@ -622,7 +622,8 @@ __global__ __launch_bounds__(256) void k_nms_csr_fill(const u64 *__restrict__ ma
     const int s = (int)(t - i * SW);
     if (i >= n) return;
     const int ib = (int)(i >> 6), r = (int)(i & 63);
-    if (s < (ib >> 6)) return;
+    const int SWn = (((n + 63) >> 6) + 63) >> 6;                 // summary words the mask phase wrote for this image
+    if (s < (ib >> 6) || s >= SWn) return;
     u64 bits = csr_live_bits(rsum[((int64_t)img * Np + i) * SW + s], s, ib);
     const int c = __builtin_popcountll(bits);
     if (!c) return;
@@ -657,7 +658,8 @@ __global__ __launch_bounds__(256) void k_nms_csr_fill_wave(const u64 *__restrict
     if (i0 >= n) return;
     const int ib = (int)(i0 >> 6), r = (int)(i & 63);
     u64 bits = 0;
-    if (i < n && s >= (ib >> 6)) bits = csr_live_bits(rsum[((int64_t)img * Np + i) * SW + s], s, ib);
+    const int SWn = (((n + 63) >> 6) + 63) >> 6;                 // summary words the mask phase wrote for this image
+    if (i < n && s >= (ib >> 6) && s < SWn) bits = csr_live_bits(rsum[((int64_t)img * Np + i) * SW + s], s, ib);
     const int c = __builtin_popcountll(bits);
     int incl = c;
 #pragma unroll
