@@ -474,3 +474,58 @@ def test_kmeans_sharded_equals_single(va, oracle):
     assert torch.equal(total, acc) and torch.equal(labels, lab2)
     want = oracle.kmeans_step(wh, cent0, np.full(wh.shape[0], 255, np.uint8))
     assert np.array_equal(acc.cpu().numpy(), want)
+
+
+def _km_adversarial_boxes(seed, n, cent):
+    """boxes that stress the assignment pre-filter: exact and near ties, tiny overlaps, copies of the centroids,
+    zero-size, negative and very large boxes, next to ordinary ones."""
+    rng = np.random.default_rng(seed)
+    wh = np.exp(rng.normal(0.0, 1.0, (n, 2))).astype(np.float32)
+    m = n // 8
+    wh[:m] = np.exp(rng.normal(0.0, 4.0, (m, 2))).astype(np.float32)                      # IoU far below 1/32 for many
+    s = np.exp(rng.normal(0.0, 1.0, m)).astype(np.float32)
+    wh[m:2 * m] = np.stack([s, s], 1)                                                       # exact ties for mirrored centroids
+    small = np.flatnonzero(cent.max(1) < 1e6)                   # x * 2^32 has to stay inside int64
+    pick = small[rng.integers(0, small.size, m)]
+    wh[2 * m:3 * m] = cent[pick] * (1 + rng.integers(-2, 3, (m, 2)) * np.float32(2.0 ** -23))  # within ulps of a centroid
+    wh[3 * m:3 * m + 64] = 0.0
+    wh[3 * m + 64:3 * m + 128] = np.float32(1e6) * (1 + rng.random((64, 2), dtype=np.float32))  # past the fast conversion range
+    wh[3 * m + 128:3 * m + 192] *= -1.0
+    wh[3 * m + 192:3 * m + 256] = np.float32(1e-7)
+    return wh[rng.permutation(n)]
+
+
+@pytest.mark.parametrize("name,cent", [
+    ("mirrored", [[0.5, 2.0], [2.0, 0.5], [1.0, 1.0], [3.0, 3.0], [0.25, 0.25]]),
+    ("near_duplicate", [[1.0, 1.0], [1.0, 1.0 + 2.0 ** -20], [1.0 + 2.0 ** -22, 1.0], [2.0, 0.5], [0.5, 2.0]]),
+    ("duplicate", [[1.0, 1.0], [1.0, 1.0], [2.0, 2.0], [2.0, 2.0], [0.5, 0.5]]),
+    ("huge_centroid", [[1.0, 1.0], [2.0 ** 31, 2.0 ** 31], [2.0, 0.5], [0.5, 2.0], [3.0, 3.0]]),
+    ("k4", [[0.5, 2.0], [2.0, 0.5], [1.0, 1.0], [3.0, 3.0]]),
+    ("k9", [[0.5, 2.0], [2.0, 0.5], [1.0, 1.0], [3.0, 3.0], [0.25, 0.25], [1.0, 3.0], [3.0, 1.0], [0.7, 0.7], [1.5, 1.5]]),
+    ("k12", [[0.5, 2.0], [2.0, 0.5], [1.0, 1.0], [3.0, 3.0], [0.25, 0.25], [1.0, 3.0], [3.0, 1.0], [0.7, 0.7], [1.5, 1.5],
+             [1.5, 1.5], [0.1, 5.0], [5.0, 0.1]]),
+])
+def test_kmeans_step_adversarial(va, oracle, name, cent):
+    """the approximate pre-filter may only ever skip work, never change a label, a sum or the inertia."""
+    from vision_amd import ops
+    cent = np.asarray(cent, np.float32)
+    k = cent.shape[0]
+    wh = _km_adversarial_boxes(len(name), 1_200_003, cent)
+    x = torch.from_numpy(wh).cuda()
+    labels = torch.full((wh.shape[0],), 255, dtype=torch.uint8, device="cuda")
+    acc = torch.zeros(3 * k + 2, dtype=torch.int64, device="cuda")
+    ops.kmeans_step(x, torch.from_numpy(cent).cuda(), labels, acc)
+    lab = np.full(wh.shape[0], 255, np.uint8)
+    want = oracle.kmeans_step(wh, cent, lab)
+    assert np.array_equal(labels.cpu().numpy(), lab)
+    assert np.array_equal(acc.cpu().numpy(), want)
+    # an 8-byte-offset shard start (head peel) and an odd tail give the same answer
+    acc2 = torch.zeros_like(acc)
+    lab2 = torch.full((wh.shape[0] - 1,), 255, dtype=torch.uint8, device="cuda")
+    ops.kmeans_step(x[1:], torch.from_numpy(cent).cuda(), lab2, acc2)
+    lab1 = np.full(1, 255, np.uint8)
+    first = oracle.kmeans_step(wh[:1], cent, lab1)
+    assert np.array_equal(lab2.cpu().numpy(), lab[1:])
+    got = acc2.cpu().numpy() + first
+    got[3 * k] = want[3 * k]                                     # 'changed' counts are per call
+    assert np.array_equal(got, want)

@@ -30,55 +30,130 @@ __device__ __forceinline__ long long wave_sum_ll(long long v)
 // a lane-private word cost ~6 LDS cycles and run beside the VALU, where 3*k predicated 64-bit register adds
 // (half-rate v_cndmask) were the larger half of the kernel.  Addresses differ only by multiples of 2 KiB between
 // clusters, so every wave access is conflict-free whatever the labels are.
-template <int KMAX>
-__device__ __forceinline__ void km_one(float w, float h, const float (&cw)[KMAX], const float (&ch)[KMAX], int k,
-                                       unsigned long long *sacc, unsigned *scnt, long long &inertia, int &changed,
-                                       uint8_t *lab)
+//
+// Fixed-point conversion: for |x| < 2^19, fma((double)x, 2^32, 1.5*2^52) lands in the binade whose ulp is 1, so the
+// add itself rounds x*2^32 to nearest-even and the result's bit pattern is KM_MAGIC + llrint(x*2^32).  The raw bit
+// patterns are summed (mod 2^64) and count*KM_MAGIC is taken off once per workgroup: two f64 ops per value instead
+// of the ten of a double->int64 conversion.  Values outside that range (or NaN) take the plain conversion, biased
+// by KM_MAGIC so the bookkeeping stays uniform.
+#define KM_MAGIC 0x4338000000000000ull
+#define KM_FAST_LIMIT 524288.0f
+
+template <int KMAX, bool FULL>
+__device__ __forceinline__ int km_assign(float w, float h, const float (&cw)[KMAX], const float (&ch)[KMAX], int k, float &bd)
 {
     int best = 0;
-    float bd = kdist(w, h, cw[0], ch[0]);
+    bd = kdist(w, h, cw[0], ch[0]);
 #pragma unroll
     for (int c = 1; c < KMAX; ++c) {
-        if (c < k) {
+        if (FULL || c < k) {
             float d = kdist(w, h, cw[c], ch[c]);
             if (d < bd) { bd = d; best = c; }
         }
     }
-    atomicAdd(&sacc[(best * 2 + 0) * KM_BLOCK], (unsigned long long)fx32(w));
-    atomicAdd(&sacc[(best * 2 + 1) * KM_BLOCK], (unsigned long long)fx32(h));
+    return best;
+}
+
+// Assignment pre-filter.  The five IEEE divisions of km_assign are two thirds of the kernel, yet the winner is
+// rarely in doubt: a = inter * rcp(uni) is within 1.5 * 2^-23 (relative) of the exact quotient q.  The cluster index
+// replaces the low four mantissa bits (another 15 ulp), and an unsigned max / median-of-three pair keeps the two
+// largest keys m1 >= m2.  When m1 - m2 > 256 ulp (>= 2^-16 relative) and m1 >= 2^-5, the exact quotients differ by
+// more than q * 2^-17 >= 2^-22, i.e. by several ulps of d = fl(1 - q): that cluster wins the exact comparison
+// strictly, whatever the index order, and only its d is evaluated exactly.  Anything else (near ties, tiny overlaps,
+// NaN/inf/negative keys, which the unsigned max drags into m1) takes km_assign.  Callers bound |w|+|h| < 2^19 and
+// centroid areas < 2^60 so that rcp(uni) stays a normal number.
+#define KM_GAP_MIN 256u
+#define KM_KEY_LO 0x3D000000u           /* 2^-5 */
+#define KM_KEY_HI 0x7F800000u           /* +inf: NaN and sign-bit keys compare above it */
+__device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+template <int KMAX, bool FULL>
+__device__ __forceinline__ bool km_filter(float w, float h, const float (&cw)[KMAX], const float (&ch)[KMAX], int k, unsigned gap_min,
+                                          int &best)
+{
+    const float area = w * h;
+    unsigned m1 = 0, m2 = 0;
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c) {
+        if (FULL || c < k) {
+            const float inter = fminf(w, cw[c]) * fminf(h, ch[c]);
+            const float uni = (area + (cw[c] * ch[c])) - inter;
+            const unsigned key = (__float_as_uint(inter * __builtin_amdgcn_rcpf(uni)) & ~15u) | (unsigned)c;
+            m2 = umed3(m1, m2, key);
+            m1 = max(m1, key);
+        }
+    }
+    best = (int)(m1 & 15u);
+    return (m1 - m2 > gap_min) && (m1 - KM_KEY_LO < KM_KEY_HI - KM_KEY_LO);
+}
+
+template <bool FAST>
+__device__ __forceinline__ unsigned long long fx32_biased(float v)
+{
+    if (FAST) return (unsigned long long)__double_as_longlong(fma((double)v, 4294967296.0, 6755399441055744.0));
+    return (unsigned long long)fx32(v) + KM_MAGIC;
+}
+
+template <bool FAST>
+__device__ __forceinline__ void km_accum(float w, float h, float bd, int best, unsigned long long *sacc, unsigned *scnt,
+                                         unsigned long long &inertia, int &changed, uint8_t *lab)
+{
+    atomicAdd(&sacc[(best * 2 + 0) * KM_BLOCK], fx32_biased<FAST>(w));
+    atomicAdd(&sacc[(best * 2 + 1) * KM_BLOCK], fx32_biased<FAST>(h));
     atomicAdd(&scnt[best * KM_BLOCK], 1u);
-    inertia += fx32(bd);
+    inertia += fx32_biased<FAST>(bd);
     changed += (*lab != (uint8_t)best);
     *lab = (uint8_t)best;
 }
 
-template <int KMAX>
+template <int KMAX, bool FULL>
+__device__ __forceinline__ void km_one(float w, float h, const float (&cw)[KMAX], const float (&ch)[KMAX], int k,
+                                       unsigned long long *sacc, unsigned *scnt, unsigned long long &inertia, int &changed,
+                                       uint8_t *lab)
+{
+    float bd;
+    const int best = km_assign<KMAX, FULL>(w, h, cw, ch, k, bd);
+    if ((fabsf(w) + fabsf(h)) + fabsf(bd) < KM_FAST_LIMIT) km_accum<true>(w, h, bd, best, sacc, scnt, inertia, changed, lab);
+    else km_accum<false>(w, h, bd, best, sacc, scnt, inertia, changed, lab);
+}
+
+template <int KMAX, bool FULL>
 __global__ __launch_bounds__(KM_BLOCK) void k_kmeans_step(const float2 *__restrict__ wh, int64_t n, const float *__restrict__ cent,
                                                           int k, uint8_t *__restrict__ labels, long long *__restrict__ partials)
 {
     __shared__ unsigned long long sacc_all[KMAX * 2 * KM_BLOCK];
     __shared__ unsigned scnt_all[KMAX * KM_BLOCK];
     __shared__ long long red[KM_BLOCK / 64][3 * KMAX + 2];
+    __shared__ float2 scent[16];
     const int tid = threadIdx.x;
     float cw[KMAX], ch[KMAX];
+    bool cent_ok = true;
 #pragma unroll
     for (int c = 0; c < KMAX; ++c) {
         cw[c] = (c < k) ? cent[2 * c] : 0.f;
         ch[c] = (c < k) ? cent[2 * c + 1] : 0.f;
+        cent_ok = cent_ok && (fabsf(cw[c] * ch[c]) < 0x1p60f);
         sacc_all[(c * 2 + 0) * KM_BLOCK + tid] = 0;
         sacc_all[(c * 2 + 1) * KM_BLOCK + tid] = 0;
         scnt_all[c * KM_BLOCK + tid] = 0;
     }
+    if (tid < 16) scent[tid] = (tid < k) ? make_float2(cent[2 * tid], cent[2 * tid + 1]) : make_float2(0.f, 0.f);
+    __syncthreads();
+    const unsigned gap_min = cent_ok ? KM_GAP_MIN : 0xffffffffu;     // a gap nobody reaches: exact path only
     unsigned long long *sacc = sacc_all + tid;     // lane-private column: no barrier needed until the final reduce
     unsigned *scnt = scnt_all + tid;
-    long long inertia = 0;
+    unsigned long long inertia = 0;                // biased like the LDS sums: KM_MAGIC per box
     int changed = 0;
 
     // two boxes per lane per 16-byte load, two loads in flight; an 8-byte-aligned shard start is peeled off first
     const int head = ((reinterpret_cast<uintptr_t>(wh) & 8) && n > 0) ? 1 : 0;
     if (head && blockIdx.x == 0 && tid == 0) {
-        const float2 a = wh[0];
-        km_one<KMAX>(a.x, a.y, cw, ch, k, sacc, scnt, inertia, changed, labels);
+        const float2 t = wh[0];
+        km_one<KMAX, FULL>(t.x, t.y, cw, ch, k, sacc, scnt, inertia, changed, labels);
     }
     wh += head; n -= head;
     const int64_t npair = n >> 1;
@@ -86,34 +161,67 @@ __global__ __launch_bounds__(KM_BLOCK) void k_kmeans_step(const float2 *__restri
     uint8_t *lab = labels + head;
     const int64_t stride = (int64_t)gridDim.x * KM_BLOCK;
     int64_t i = (int64_t)blockIdx.x * KM_BLOCK + tid;
-    for (; i + stride < npair; i += 2 * stride) {
-        const float4 a = wh4[i], b = wh4[i + stride];
-        km_one<KMAX>(a.x, a.y, cw, ch, k, sacc, scnt, inertia, changed, lab + 2 * i);
-        km_one<KMAX>(a.z, a.w, cw, ch, k, sacc, scnt, inertia, changed, lab + 2 * i + 1);
-        km_one<KMAX>(b.x, b.y, cw, ch, k, sacc, scnt, inertia, changed, lab + 2 * (i + stride));
-        km_one<KMAX>(b.z, b.w, cw, ch, k, sacc, scnt, inertia, changed, lab + 2 * (i + stride) + 1);
+    bool have = i + stride < npair;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    if (have) { a = wh4[i]; b = wh4[i + stride]; }
+    while (have) {
+        // the next pair of loads is issued before this pair is worked on
+        const int64_t inext = i + 2 * stride;
+        const bool more = inext + stride < npair;
+        float4 na = a, nb = b;
+        if (more) { na = wh4[inext]; nb = wh4[inext + stride]; }
+        float d0, d1, d2, d3;
+        int b0, b1, b2, b3;
+        const float magwh = ((fabsf(a.x) + fabsf(a.y)) + (fabsf(a.z) + fabsf(a.w))) + ((fabsf(b.x) + fabsf(b.y)) + (fabsf(b.z) + fabsf(b.w)));
+        const bool f0 = km_filter<KMAX, FULL>(a.x, a.y, cw, ch, k, gap_min, b0), f1 = km_filter<KMAX, FULL>(a.z, a.w, cw, ch, k, gap_min, b1);
+        const bool f2 = km_filter<KMAX, FULL>(b.x, b.y, cw, ch, k, gap_min, b2), f3 = km_filter<KMAX, FULL>(b.z, b.w, cw, ch, k, gap_min, b3);
+        if ((f0 && f1) && (f2 && f3) && magwh < KM_FAST_LIMIT) {
+            const float2 c0 = scent[b0], c1 = scent[b1], c2 = scent[b2], c3 = scent[b3];
+            d0 = kdist(a.x, a.y, c0.x, c0.y); d1 = kdist(a.z, a.w, c1.x, c1.y);
+            d2 = kdist(b.x, b.y, c2.x, c2.y); d3 = kdist(b.z, b.w, c3.x, c3.y);
+        } else {
+            b0 = km_assign<KMAX, FULL>(a.x, a.y, cw, ch, k, d0); b1 = km_assign<KMAX, FULL>(a.z, a.w, cw, ch, k, d1);
+            b2 = km_assign<KMAX, FULL>(b.x, b.y, cw, ch, k, d2); b3 = km_assign<KMAX, FULL>(b.z, b.w, cw, ch, k, d3);
+        }
+        // one range test for the four boxes: every term is >= 0, so a sum below the limit bounds each of them
+        const float mag = magwh + ((fabsf(d0) + fabsf(d1)) + (fabsf(d2) + fabsf(d3)));
+        if (mag < KM_FAST_LIMIT) {
+            km_accum<true>(a.x, a.y, d0, b0, sacc, scnt, inertia, changed, lab + 2 * i);
+            km_accum<true>(a.z, a.w, d1, b1, sacc, scnt, inertia, changed, lab + 2 * i + 1);
+            km_accum<true>(b.x, b.y, d2, b2, sacc, scnt, inertia, changed, lab + 2 * (i + stride));
+            km_accum<true>(b.z, b.w, d3, b3, sacc, scnt, inertia, changed, lab + 2 * (i + stride) + 1);
+        } else {
+            km_accum<false>(a.x, a.y, d0, b0, sacc, scnt, inertia, changed, lab + 2 * i);
+            km_accum<false>(a.z, a.w, d1, b1, sacc, scnt, inertia, changed, lab + 2 * i + 1);
+            km_accum<false>(b.x, b.y, d2, b2, sacc, scnt, inertia, changed, lab + 2 * (i + stride));
+            km_accum<false>(b.z, b.w, d3, b3, sacc, scnt, inertia, changed, lab + 2 * (i + stride) + 1);
+        }
+        i = inext; a = na; b = nb; have = more;
     }
     for (; i < npair; i += stride) {
-        const float4 a = wh4[i];
-        km_one<KMAX>(a.x, a.y, cw, ch, k, sacc, scnt, inertia, changed, lab + 2 * i);
-        km_one<KMAX>(a.z, a.w, cw, ch, k, sacc, scnt, inertia, changed, lab + 2 * i + 1);
+        const float4 t = wh4[i];
+        km_one<KMAX, FULL>(t.x, t.y, cw, ch, k, sacc, scnt, inertia, changed, lab + 2 * i);
+        km_one<KMAX, FULL>(t.z, t.w, cw, ch, k, sacc, scnt, inertia, changed, lab + 2 * i + 1);
     }
     if ((n & 1) && blockIdx.x == 0 && tid == 0) {
-        const float2 a = wh[n - 1];
-        km_one<KMAX>(a.x, a.y, cw, ch, k, sacc, scnt, inertia, changed, lab + (n - 1));
+        const float2 t = wh[n - 1];
+        km_one<KMAX, FULL>(t.x, t.y, cw, ch, k, sacc, scnt, inertia, changed, lab + (n - 1));
     }
 
     // block reduction: wave shuffles, then LDS across the 4 waves
     const int lane = tid & 63, wave = tid >> 6;
+    long long nbox = 0;
 #pragma unroll
     for (int c = 0; c < KMAX; ++c) {
         long long a = wave_sum_ll((long long)sacc[(c * 2 + 0) * KM_BLOCK]), b2 = wave_sum_ll((long long)sacc[(c * 2 + 1) * KM_BLOCK]);
         long long c2 = wave_sum_ll((long long)scnt[c * KM_BLOCK]);
-        if (lane == 0) { red[wave][c] = a; red[wave][KMAX + c] = b2; red[wave][2 * KMAX + c] = c2; }
+        const long long bias = (long long)((unsigned long long)c2 * KM_MAGIC);   // mod 2^64, like the sums
+        nbox += c2;
+        if (lane == 0) { red[wave][c] = a - bias; red[wave][KMAX + c] = b2 - bias; red[wave][2 * KMAX + c] = c2; }
     }
     {
-        long long a = wave_sum_ll((long long)changed), b2 = wave_sum_ll(inertia);
-        if (lane == 0) { red[wave][3 * KMAX] = a; red[wave][3 * KMAX + 1] = b2; }
+        long long a = wave_sum_ll((long long)changed), b2 = wave_sum_ll((long long)inertia);
+        if (lane == 0) { red[wave][3 * KMAX] = a; red[wave][3 * KMAX + 1] = b2 - (long long)((unsigned long long)nbox * KM_MAGIC); }
     }
     __syncthreads();
     if (tid < 3 * KMAX + 2) {
@@ -165,7 +273,22 @@ __global__ __launch_bounds__(256) void k_labels_widen(const uint8_t *__restrict_
 }
 
 static inline int km_kmax(int64_t k) { return k <= 5 ? 5 : (k <= 9 ? 9 : 16); }
-static inline int km_blocks(int64_t n) { int64_t b = dg_cdiv(n, KM_BLOCK * 4); return (int)(b < 1 ? 1 : (b > KM_MAXBLOCKS ? KM_MAXBLOCKS : b)); }
+// One resident round: as many workgroups as the device holds at once for this variant (registers and LDS decide),
+// so that no workgroup starts on a mostly idle chip after the others have finished.
+template <typename K>
+static int km_resident_blocks(K kernel)
+{
+    int per_cu = 0, dev = 0, cus = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, KM_BLOCK, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+    const int b = per_cu * cus;
+    return b > KM_MAXBLOCKS ? KM_MAXBLOCKS : b;
+}
+static inline int km_blocks(int64_t n, int resident)
+{
+    int64_t b = dg_cdiv(n, KM_BLOCK * 4);
+    return (int)(b < 1 ? 1 : (b > resident ? resident : b));
+}
 
 extern "C" size_t dg_kmeans_workspace_bytes(int64_t n, int64_t k)
 {
@@ -182,14 +305,22 @@ extern "C" int dg_kmeans_iou_step(const float *wh, int64_t n, const float *cent,
     DG_REQUIRE((((uintptr_t)wh) & 7) == 0 && (((uintptr_t)ws) & 7) == 0, "kmeans_step: misaligned pointer");
     if (ws_bytes < dg_kmeans_workspace_bytes(n, k)) { dg_set_error("kmeans_step: workspace too small"); return DG_ENOMEM; }
     hipStream_t st = (hipStream_t)s;
-    const int kmax = km_kmax(k), nb = km_blocks(n);
+    const int kmax = km_kmax(k);
+    int nb = 1;
     long long *partials = (long long *)ws;
-    if (kmax == 5)
-        hipLaunchKernelGGL((k_kmeans_step<5>), dim3(nb), dim3(KM_BLOCK), 0, st, (const float2 *)wh, n, cent, (int)k, labels, partials);
-    else if (kmax == 9)
-        hipLaunchKernelGGL((k_kmeans_step<9>), dim3(nb), dim3(KM_BLOCK), 0, st, (const float2 *)wh, n, cent, (int)k, labels, partials);
-    else
-        hipLaunchKernelGGL((k_kmeans_step<16>), dim3(nb), dim3(KM_BLOCK), 0, st, (const float2 *)wh, n, cent, (int)k, labels, partials);
+#define KM_LAUNCH(KM, FULL)                                                                                                          \
+    do {                                                                                                                             \
+        static const int resident = km_resident_blocks(k_kmeans_step<KM, FULL>);                                                     \
+        nb = km_blocks(n, resident);                                                                                                 \
+        hipLaunchKernelGGL((k_kmeans_step<KM, FULL>), dim3(nb), dim3(KM_BLOCK), 0, st, (const float2 *)wh, n, cent, (int)k, labels, partials); \
+    } while (0)
+    // k == 5 and k == 9 (the YOLOv2 anchor counts) get kernels without the per-cluster `c < k` branches
+    if (k == 5) KM_LAUNCH(5, true);
+    else if (kmax == 5) KM_LAUNCH(5, false);
+    else if (k == 9) KM_LAUNCH(9, true);
+    else if (kmax == 9) KM_LAUNCH(9, false);
+    else KM_LAUNCH(16, false);
+#undef KM_LAUNCH
     hipLaunchKernelGGL(k_kmeans_finish, dim3(3 * kmax + 2), dim3(256), 0, st, partials, nb, kmax, (int)k, (long long *)acc);
     DG_CHECK_LAUNCH("k_kmeans_step");
     return DG_OK;
