@@ -122,14 +122,17 @@ int dg_roipool_bwd_f32(const float *grad_out, const int32_t *argmax, const int32
  * Lloyd step is build-defined (spec: oracle/oracle.c orc_kmeans_step / SURVEY.md §8(a) K1).
  * wh (n,2) fp32; cent (k,2) fp32; labels (n) uint8 in/out; acc (3k+2) int64 =
  * {sum_w[k], sum_h[k], count[k], changed, inertia_fx} is OVERWRITTEN with this shard's sums
- * (all-reduce it across ranks, then call dg_kmeans_update).  k <= 16. */
+ * (all-reduce it across ranks, then call dg_kmeans_update).  k <= 16.  wh 8-byte and ws 16-byte aligned;
+ * |w|, |h| < 2^31 (the fixed-point sums hold x * 2^32 in int64).  One launch: the workgroup that finishes
+ * last folds the per-workgroup rows held in ws.  Calls that share a workspace must be stream-ordered. */
 size_t dg_kmeans_workspace_bytes(int64_t n, int64_t k);
 int dg_kmeans_iou_step(const float *wh, int64_t n, const float *cent, int64_t k, uint8_t *labels, int64_t *acc,
                        void *ws, size_t ws_bytes, dg_stream_t s);
 /* centroid = sum/count (int64 fixed point 2^32 -> fp32); empty cluster keeps its centroid.
  * history (may be NULL): history[slot] = acc[3k] (changed count of this iteration). */
 int dg_kmeans_update(const int64_t *acc, int64_t k, float *cent, int64_t *history, int64_t slot, dg_stream_t s);
-/* `iters` iterations of step+update back to back on ONE device (no all-reduce): history[slot0+t] = changed count. */
+/* `iters` iterations of step+update back to back on ONE device (no all-reduce), one launch per iteration:
+ * history[slot0+t] = changed count. */
 int dg_kmeans_iou_run(const float *wh, int64_t n, float *cent, int64_t k, uint8_t *labels, int64_t *acc,
                       int64_t *history, int64_t slot0, int64_t iters, void *ws, size_t ws_bytes, dg_stream_t s);
 int dg_kmeans_labels_i32(const uint8_t *labels, int64_t n, int32_t *out, dg_stream_t s);

@@ -4,7 +4,8 @@ import sys, time
 import torch
 sys.path.insert(0, ".")
 from vision_amd import cluster, workloads as wl
-wh = torch.from_numpy(wl.anchor_wh(0, 1_250_000)).cuda()       # one rank's shard at 8 GPUs
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_250_000         # default: one rank's shard at 8 GPUs
+wh = torch.from_numpy(wl.anchor_wh(0, n)).cuda()
 init = cluster.kmean.init_centers(wh.cpu().numpy(), 5, 42)
 km = cluster.kmean(5, 42); km.fit(wh, init_centers=init, fixed_iters=30)
 def t(fn):

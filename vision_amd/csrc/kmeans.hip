@@ -4,8 +4,8 @@
 //   d = 1 - inter/((w*h + cw*ch) - inter), fp32, ties -> lowest index; sums in int64 fixed point
 //   (llrint(x * 2^32)) so any sharding / reduction order gives identical bits.
 // Step kernel: grid-stride, two boxes per lane per 16-byte load, centroids in SGPRs, per-lane
-// int64 partial sums in registers -> wave shuffle reduce -> LDS -> one partial row per workgroup
-// (plain stores); a single-workgroup finish kernel folds the rows into acc[3k+2].
+// partial sums in LDS -> wave shuffle reduce -> one partial row per workgroup (plain stores); the workgroup
+// that finishes last folds the rows into acc[3k+2] and, in the device-side loop, updates the centroids.
 #include "common.hpp"
 
 #define KM_BLOCK 256
@@ -122,9 +122,12 @@ __device__ __forceinline__ void km_one(float w, float h, const float (&cw)[KMAX]
 }
 
 template <int KMAX, bool FULL>
-__global__ __launch_bounds__(KM_BLOCK) void k_kmeans_step(const float2 *__restrict__ wh, int64_t n, const float *__restrict__ cent,
-                                                          int k, uint8_t *__restrict__ labels, long long *__restrict__ partials)
+__global__ __launch_bounds__(KM_BLOCK) void k_kmeans_step(const float2 *__restrict__ wh, int64_t n, const float *cent, int k,
+                                                          uint8_t *__restrict__ labels, long long *partials, unsigned *ticket,
+                                                          long long *__restrict__ acc, float *cent_out, long long *__restrict__ history,
+                                                          int64_t slot)
 {
+    constexpr int COLS = 3 * KMAX + 2, CP = (COLS + 1) & ~1;      // a row is padded to whole 16-byte pairs
     __shared__ unsigned long long sacc_all[KMAX * 2 * KM_BLOCK];
     __shared__ unsigned scnt_all[KMAX * KM_BLOCK];
     __shared__ long long red[KM_BLOCK / 64][3 * KMAX + 2];
@@ -224,31 +227,78 @@ __global__ __launch_bounds__(KM_BLOCK) void k_kmeans_step(const float2 *__restri
         if (lane == 0) { red[wave][3 * KMAX] = a; red[wave][3 * KMAX + 1] = b2 - (long long)((unsigned long long)nbox * KM_MAGIC); }
     }
     __syncthreads();
-    if (tid < 3 * KMAX + 2) {
+    if (tid < CP) {
         long long v = 0;
+        if (tid < COLS) {
 #pragma unroll
-        for (int w = 0; w < KM_BLOCK / 64; ++w) v += red[w][tid];
-        partials[(int64_t)blockIdx.x * (3 * KMAX + 2) + tid] = v;
+            for (int w = 0; w < KM_BLOCK / 64; ++w) v += red[w][tid];
+        }
+        // Device-scope (write-through) store, completed before the ticket is drawn.  A __threadfence() here costs a
+        // sweep of the XCD's whole L2 per workgroup (+24 us per launch when every workgroup does one).
+        __hip_atomic_store(&partials[(int64_t)blockIdx.x * CP + tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-}
 
-// folds the per-workgroup rows (layout with KMAX columns) into acc (layout with k columns); one workgroup per column
-__global__ __launch_bounds__(256) void k_kmeans_finish(const long long *__restrict__ partials, int nblocks, int KMAX, int k,
-                                                       long long *__restrict__ acc)
-{
-    __shared__ long long red[4];
-    const int cols = 3 * KMAX + 2, col = blockIdx.x;
-    long long v = 0;
-    for (int r = threadIdx.x; r < nblocks; r += 256) v += partials[(int64_t)r * cols + col];
-    v = wave_sum_ll(v);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    // The workgroup that draws the last ticket folds all rows (and, inside dg_kmeans_iou_run, moves the centroids):
+    // one launch per Lloyd iteration instead of three.  The ticket returns to zero for the next launch.
+    __shared__ unsigned s_ticket;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const long long t = (red[0] + red[1]) + (red[2] + red[3]);
-        const int grp = col / KMAX, c = col - grp * KMAX;
-        if (grp < 3) { if (c < k) acc[grp * k + c] = t; }
-        else acc[3 * k + c] = t;                    // changed, inertia
+    if (tid == 0) s_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (s_ticket != gridDim.x - 1) return;
+    unsigned long long *s_tot = sacc_all;                  // the accumulators are spent; reuse their LDS
+    if (tid < CP) s_tot[tid] = 0;
+    __syncthreads();
+    {
+        // Device-scope loads (sc1): the rows were written from every XCD and must not come from this XCD's L2.
+        // Thirty-two are issued before the first is used; as atomic loads the compiler would wait for each in turn.
+        // A thread strides by a multiple of the row length, so all its values belong to one column and meet in a register.
+        constexpr int ACTIVE = (KM_BLOCK / CP) * CP;
+        const int nvals = (int)gridDim.x * CP;
+        if (tid < ACTIVE) {
+            long long sum = 0;
+            for (int base = tid; base < nvals; base += 32 * ACTIVE) {
+                long long v[32];
+#pragma unroll
+                for (int j = 0; j < 32; ++j) {
+                    const int p = base + j * ACTIVE;
+                    const long long *ptr = partials + (p < nvals ? p : 0);
+                    asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=&v"(v[j]) : "v"(ptr) : "memory");
+                }
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                               "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
+                             :
+                             : "memory");
+                asm volatile(""
+                             : "+v"(v[16]), "+v"(v[17]), "+v"(v[18]), "+v"(v[19]), "+v"(v[20]), "+v"(v[21]), "+v"(v[22]), "+v"(v[23]),
+                               "+v"(v[24]), "+v"(v[25]), "+v"(v[26]), "+v"(v[27]), "+v"(v[28]), "+v"(v[29]), "+v"(v[30]), "+v"(v[31])
+                             :
+                             : "memory");
+#pragma unroll
+                for (int j = 0; j < 32; ++j) sum += (base + j * ACTIVE < nvals) ? v[j] : 0;
+            }
+            atomicAdd(&s_tot[tid % CP], (unsigned long long)sum);
+        }
     }
+    __syncthreads();
+    if (tid < COLS) {
+        const long long t = (long long)s_tot[tid];
+        const int grp = tid / KMAX, c = tid - grp * KMAX;
+        if (grp < 3) { if (c < k) acc[grp * k + c] = t; }
+        else acc[3 * k + c] = t;                           // changed, inertia
+    }
+    if (cent_out) {                                        // same arithmetic as k_kmeans_update
+        if (tid < k) {
+            const long long cnt = (long long)s_tot[2 * KMAX + tid];
+            if (cnt > 0) {
+                cent_out[2 * tid] = (float)((double)(long long)s_tot[tid] / (double)cnt / 4294967296.0);
+                cent_out[2 * tid + 1] = (float)((double)(long long)s_tot[KMAX + tid] / (double)cnt / 4294967296.0);
+            }
+        }
+        if (tid == 0 && history) history[slot] = (long long)s_tot[3 * KMAX];
+    }
+    if (tid == 0) *ticket = 0;
 }
 
 __global__ void k_kmeans_update(const long long *__restrict__ acc, int k, float *__restrict__ cent,
@@ -293,26 +343,22 @@ static inline int km_blocks(int64_t n, int resident)
 extern "C" size_t dg_kmeans_workspace_bytes(int64_t n, int64_t k)
 {
     if (n < 0 || k <= 0 || k > 16) return 0;
-    return (size_t)KM_MAXBLOCKS * (3 * 16 + 2) * 8;
+    return (size_t)KM_MAXBLOCKS * (3 * 16 + 2) * 8 + 16;     // rows + the ticket
 }
+static inline unsigned *km_ticket(void *ws) { return (unsigned *)((char *)ws + (size_t)KM_MAXBLOCKS * (3 * 16 + 2) * 8); }
 
-extern "C" int dg_kmeans_iou_step(const float *wh, int64_t n, const float *cent, int64_t k, uint8_t *labels, int64_t *acc,
-                                  void *ws, size_t ws_bytes, dg_stream_t s)
+// step (+ fold) as one launch; with cent_out the last workgroup also writes the new centroids and history[slot]
+static int km_launch(const float *wh, int64_t n, const float *cent, int64_t k, uint8_t *labels, int64_t *acc, float *cent_out,
+                     int64_t *history, int64_t slot, void *ws, hipStream_t st)
 {
-    DG_REQUIRE(n >= 0 && k >= 1 && k <= 16, "kmeans_step: need n >= 0 and 1 <= k <= 16");
-    DG_REQUIRE(cent && acc && ws, "kmeans_step: null pointer");
-    DG_REQUIRE(n == 0 || (wh && labels), "kmeans_step: null pointer");
-    DG_REQUIRE((((uintptr_t)wh) & 7) == 0 && (((uintptr_t)ws) & 7) == 0, "kmeans_step: misaligned pointer");
-    if (ws_bytes < dg_kmeans_workspace_bytes(n, k)) { dg_set_error("kmeans_step: workspace too small"); return DG_ENOMEM; }
-    hipStream_t st = (hipStream_t)s;
     const int kmax = km_kmax(k);
-    int nb = 1;
     long long *partials = (long long *)ws;
-#define KM_LAUNCH(KM, FULL)                                                                                                          \
-    do {                                                                                                                             \
-        static const int resident = km_resident_blocks(k_kmeans_step<KM, FULL>);                                                     \
-        nb = km_blocks(n, resident);                                                                                                 \
-        hipLaunchKernelGGL((k_kmeans_step<KM, FULL>), dim3(nb), dim3(KM_BLOCK), 0, st, (const float2 *)wh, n, cent, (int)k, labels, partials); \
+#define KM_LAUNCH(KM, FULL)                                                                                                     \
+    do {                                                                                                                        \
+        static const int resident = km_resident_blocks(k_kmeans_step<KM, FULL>);                                                \
+        hipLaunchKernelGGL((k_kmeans_step<KM, FULL>), dim3(km_blocks(n, resident)), dim3(KM_BLOCK), 0, st, (const float2 *)wh,  \
+                           n, cent, (int)k, labels, partials, km_ticket(ws), (long long *)acc, cent_out, (long long *)history,  \
+                           slot);                                                                                               \
     } while (0)
     // k == 5 and k == 9 (the YOLOv2 anchor counts) get kernels without the per-cluster `c < k` branches
     if (k == 5) KM_LAUNCH(5, true);
@@ -321,9 +367,30 @@ extern "C" int dg_kmeans_iou_step(const float *wh, int64_t n, const float *cent,
     else if (kmax == 9) KM_LAUNCH(9, false);
     else KM_LAUNCH(16, false);
 #undef KM_LAUNCH
-    hipLaunchKernelGGL(k_kmeans_finish, dim3(3 * kmax + 2), dim3(256), 0, st, partials, nb, kmax, (int)k, (long long *)acc);
     DG_CHECK_LAUNCH("k_kmeans_step");
     return DG_OK;
+}
+
+static int km_check(const float *wh, int64_t n, const float *cent, int64_t k, const uint8_t *labels, const int64_t *acc, const void *ws,
+                    size_t ws_bytes)
+{
+    DG_REQUIRE(n >= 0 && k >= 1 && k <= 16, "kmeans_step: need n >= 0 and 1 <= k <= 16");
+    DG_REQUIRE(cent && acc && ws, "kmeans_step: null pointer");
+    DG_REQUIRE(n == 0 || (wh && labels), "kmeans_step: null pointer");
+    DG_REQUIRE((((uintptr_t)wh) & 7) == 0 && (((uintptr_t)ws) & 15) == 0, "kmeans_step: misaligned pointer");
+    if (ws_bytes < dg_kmeans_workspace_bytes(n, k)) { dg_set_error("kmeans_step: workspace too small"); return DG_ENOMEM; }
+    return DG_OK;
+}
+
+extern "C" int dg_kmeans_iou_step(const float *wh, int64_t n, const float *cent, int64_t k, uint8_t *labels, int64_t *acc,
+                                  void *ws, size_t ws_bytes, dg_stream_t s)
+{
+    int rc = km_check(wh, n, cent, k, labels, acc, ws, ws_bytes);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)s;
+    // the workspace arrives with arbitrary contents
+    if (hipMemsetAsync(km_ticket(ws), 0, 16, st) != hipSuccess) { dg_set_error("kmeans_step: memset failed"); return DG_EHIP; }
+    return km_launch(wh, n, cent, k, labels, acc, nullptr, nullptr, 0, ws, st);
 }
 
 extern "C" int dg_kmeans_update(const int64_t *acc, int64_t k, float *cent, int64_t *history, int64_t slot, dg_stream_t s)
@@ -335,17 +402,20 @@ extern "C" int dg_kmeans_update(const int64_t *acc, int64_t k, float *cent, int6
     return DG_OK;
 }
 
-// `iters` Lloyd iterations back to back on one device (step + finish + update per iteration, no host round trip);
+// `iters` Lloyd iterations back to back on one device (one launch per iteration, no host round trip);
 // history[slot0 + t] = changed count of iteration t.  A converged iteration reproduces the same centroids, so
 // running past convergence is idempotent and n_iter_ is read from the history afterwards.
 extern "C" int dg_kmeans_iou_run(const float *wh, int64_t n, float *cent, int64_t k, uint8_t *labels, int64_t *acc,
                                  int64_t *history, int64_t slot0, int64_t iters, void *ws, size_t ws_bytes, dg_stream_t s)
 {
     DG_REQUIRE(iters >= 0, "kmeans_run: iters < 0");
+    int rc = km_check(wh, n, cent, k, labels, acc, ws, ws_bytes);
+    if (rc) return rc;
+    if (iters == 0) return DG_OK;
+    hipStream_t st = (hipStream_t)s;
+    if (hipMemsetAsync(km_ticket(ws), 0, 16, st) != hipSuccess) { dg_set_error("kmeans_run: memset failed"); return DG_EHIP; }
     for (int64_t t = 0; t < iters; ++t) {
-        int rc = dg_kmeans_iou_step(wh, n, cent, k, labels, acc, ws, ws_bytes, s);
-        if (rc) return rc;
-        rc = dg_kmeans_update(acc, k, cent, history, slot0 + t, s);
+        rc = km_launch(wh, n, cent, k, labels, acc, cent, history, slot0 + t, ws, st);
         if (rc) return rc;
     }
     return DG_OK;
