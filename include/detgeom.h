@@ -159,6 +159,21 @@ int dg_yolo1_loss_f32(const float *modely, const float *targety, int64_t n, int6
 int dg_yolo1_encode_f64(const double *bb, const int64_t *label, int64_t n, int64_t num_classes, double *target,
                         int32_t *status, dg_stream_t s);
 
+/* VOC-style average precision ("next" row 3).  ap(detects, targets, iou_threds): yolo/yolo_v1/yolo.py:306-367.
+ * Detections: det_img (n_det) int32 image index, det_box (n_det,4) fp32 xyxy; `order` (n_det) int32 lists them by
+ * class ascending and, inside a class, by confidence descending with ties in list order (the reference's stable
+ * `sorted(..., reverse=True)`, :325); cls_off (n_classes+1) int64 bounds each class's run inside `order`.
+ * Targets: tgt_img / tgt_cls (n_tgt) int32, tgt_box (n_tgt,4) fp32; the last row listed for a (class, image) is its
+ * ground truth (:321).  ap_out (n_classes) float64 = the value the reference appends per class (NaN for a class
+ * with detections but no targets, as numpy's 0/0 gives); n_grt (n_classes) int32 = len(targets[c]) (:317), which the
+ * caller needs for the extra 0.0 the reference appends for an empty class (:314-315).  IoU >= iou_thr is a float32
+ * comparison, as torch makes it (:341).  One workgroup per class; float64 sums in the reference's order. */
+size_t dg_voc_ap_workspace_bytes(int64_t n_det, int64_t n_classes, int64_t n_images);
+int dg_voc_ap_f32(const int32_t *det_img, const float *det_box, const int32_t *order, const int64_t *cls_off,
+                  int64_t n_det, const int32_t *tgt_img, const int32_t *tgt_cls, const float *tgt_box, int64_t n_tgt,
+                  int64_t n_classes, int64_t n_images, float iou_thr, double *ap_out, int32_t *n_grt, void *ws,
+                  size_t ws_bytes, dg_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

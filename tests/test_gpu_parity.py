@@ -213,6 +213,78 @@ def test_evaluate_and_ap_golden(va, golden):
     assert np.allclose(yolo_v1.ap(det, tgt, 0.5), g["aps_iou05"], rtol=0, atol=1e-12)
 
 
+def _ap_case(seed, n_img, n_cls, per_img, empty_classes=()):
+    """detections / targets in the reference's dict-of-rows form: confidence ties, several targets per (class, image),
+    images without a target, classes without targets or without detections."""
+    rng = np.random.default_rng(seed)
+    detects = {c: [] for c in range(n_cls)}
+    targets = {c: [] for c in range(n_cls)}
+    for i in range(n_img):
+        for _ in range(int(rng.integers(0, 3))):
+            c = int(rng.integers(0, n_cls))
+            if c in empty_classes:
+                continue
+            xy = rng.uniform(0, 0.6, 2); wh = rng.uniform(0.1, 0.4, 2)
+            targets[c].append([i, 1] + np.concatenate([xy, xy + wh]).tolist())        # float64 rows, as bbox_target.tolist()
+        for _ in range(int(rng.integers(0, per_img + 1))):
+            c = int(rng.integers(0, n_cls))
+            if targets[c] and targets[c][-1][0] == i and rng.random() < 0.6:           # near the ground truth
+                g = np.array(targets[c][-1][2:])
+                b = g + rng.normal(0, 0.04, 4)
+            else:
+                xy = rng.uniform(0, 0.6, 2); b = np.concatenate([xy, xy + rng.uniform(0.05, 0.4, 2)])
+            conf = np.float32(rng.integers(1, 200) / 200.0)                            # many exact ties
+            detects[c].append([i, float(conf)] + [float(np.float32(v)) for v in b])
+    return detects, targets
+
+
+@pytest.mark.parametrize("seed,n_img,n_cls,per_img,empty", [(0, 40, 3, 3, ()), (1, 3000, 6, 4, (4,)), (2, 500, 20, 30, (0, 7))])
+def test_ap_vs_oracle(va, oracle, seed, n_img, n_cls, per_img, empty):
+    """bit-exact float64 AP per class, at thresholds that sit exactly on an IoU value (float32 >=, as torch compares)."""
+    from vision_amd import yolo_v1
+    det, tgt = _ap_case(seed, n_img, n_cls, per_img, empty)
+    if seed == 2:
+        det[3] = []                                                                    # a class with targets but no detections
+    some = [d for c in det for d in det[c] if any(t[0] == d[0] for t in tgt[c])][:50]
+    edge = 0.5
+    for d in some:                                                                     # an IoU that really occurs
+        c = next(c for c in det if d in det[c])
+        g = [t for t in tgt[c] if t[0] == d[0]][-1]
+        v = float(oracle.iou_elementwise(np.array([d[2:]], np.float32), np.array([g[2:]], np.float32))[0])
+        if 0.05 < v < 0.95:
+            edge = v
+            break
+    for thr in (0.01, 0.05, 0.5, 0.7, edge, float(np.nextafter(np.float32(edge), np.float32(1)))):
+        got = yolo_v1.ap(det, tgt, thr)
+        want = oracle.average_precision(det, tgt, thr)
+        assert len(got) == len(want)
+        assert np.array_equal(np.array(got), np.array(want, np.float64), equal_nan=True), (thr, got, want)
+
+
+def test_evaluate_and_ap_device_resident(va, oracle):
+    """decode -> NMS -> per-class rows -> AP without leaving the device equals the list-based path and the oracle."""
+    from vision_amd import yolo_v1
+    out, tgt = wl.yolo1_batch(5, 64)
+    o, t = torch.from_numpy(out).cuda(), torch.from_numpy(tgt).cuda()
+    det_l, tgt_l = yolo_v1.evaluate_batch(o, t, 5, prob_threshold=0.01, nms_threshold=0.3)
+    flat = yolo_v1.evaluate_batch_device(o, t, 5, prob_threshold=0.01, nms_threshold=0.3)
+    assert flat[0].is_cuda and flat[0].shape[0] == sum(len(v) for v in det_l.values())
+    want_det, want_tgt = oracle.evaluate_batch(out, tgt, 5, 0.01, 0.3)
+    for thr in (0.05, 0.5):
+        want = oracle.average_precision(want_det, want_tgt, thr)
+        assert np.array_equal(np.array(yolo_v1.ap_device(*flat, 5, 64, thr)), np.array(want), equal_nan=True)
+        assert np.array_equal(np.array(yolo_v1.ap(det_l, tgt_l, thr)), np.array(want), equal_nan=True)
+
+
+def test_ap_degenerate(va, oracle):
+    from vision_amd import yolo_v1
+    assert yolo_v1.ap({0: [], 1: []}, {0: [], 1: []}, 0.5) == oracle.average_precision({0: [], 1: []}, {0: [], 1: []}, 0.5)
+    det = {0: [[0, 0.9, 0.1, 0.1, 0.5, 0.5]], 1: [[5, 0.3, 0.0, 0.0, 1.0, 1.0]]}
+    tgt = {0: [[0, 1, 0.1, 0.1, 0.5, 0.5], [0, 1, 0.6, 0.6, 0.9, 0.9]], 1: []}       # the later target of image 0 wins (:321)
+    got, want = yolo_v1.ap(det, tgt, 0.5), oracle.average_precision(det, tgt, 0.5)
+    assert np.array_equal(np.array(got), np.array(want), equal_nan=True), (got, want)
+
+
 def test_decode_nms_config2_vs_oracle(va, oracle):
     """config 2 at full size (batch 64); ties between the two slots of a cell are ordered lower index first."""
     from vision_amd import yolo_v1

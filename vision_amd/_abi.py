@@ -50,6 +50,8 @@ SIGNATURES = {
     "dg_yolo1_encode_f64": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "dg_yolo1_loss_workspace_bytes": (C.c_size_t, [_i64]),
     "dg_yolo1_loss_f32": (C.c_int, [_vp, _vp, _i64, _i64, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp]),
+    "dg_voc_ap_workspace_bytes": (_sz, [_i64, _i64, _i64]),
+    "dg_voc_ap_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

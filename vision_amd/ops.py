@@ -132,6 +132,42 @@ def yolo1_loss(modely, targety, quirk_slot2=True, want_grad=True):
     return loss6, grad
 
 
+def voc_ap(det_img, det_cls, det_conf, det_box, tgt_img, tgt_cls, tgt_box, num_classes, num_images, iou_thr):
+    """VOC-style AP of yolo.py:306-367 for every class in one launch.  Detections and targets are flat device (or host)
+    arrays in the reference's list order; returns (ap float64 (C,), n_grt int32 (C,)) on the device.
+    The ordering (class, then confidence descending, stable) is two stable torch sorts; the rest is k_voc_ap."""
+    dev = _abi.device_of(det_box, tgt_box)
+    C_, I = int(num_classes), int(num_images)
+    dimg = _abi.to_dev(det_img, torch.int32, dev).reshape(-1)
+    dcls = _abi.to_dev(det_cls, torch.int64, dev).reshape(-1)
+    dconf = _abi.to_dev(det_conf, torch.float64, dev).reshape(-1)
+    dbox = _f32c(det_box, dev).reshape(-1, 4)
+    timg = _abi.to_dev(tgt_img, torch.int32, dev).reshape(-1)
+    tcls = _abi.to_dev(tgt_cls, torch.int32, dev).reshape(-1)
+    tbox = _f32c(tgt_box, dev).reshape(-1, 4)
+    n = dimg.shape[0]
+    if not (dcls.shape[0] == dconf.shape[0] == dbox.shape[0] == n) or not (timg.shape[0] == tcls.shape[0] == tbox.shape[0]):
+        raise ValueError("ap: ragged detection / target arrays")
+    if n:
+        by_conf = torch.sort(dconf, descending=True, stable=True).indices
+        by_cls = torch.sort(dcls[by_conf], stable=True).indices
+        order = by_conf[by_cls].to(torch.int32)
+        counts = torch.bincount(dcls.clamp(0, C_ - 1), minlength=C_)
+    else:
+        order = torch.empty(0, dtype=torch.int32, device=dev)
+        counts = torch.zeros(C_, dtype=torch.int64, device=dev)
+    cls_off = torch.zeros(C_ + 1, dtype=torch.int64, device=dev)
+    cls_off[1:] = torch.cumsum(counts, 0)
+    out = torch.empty(C_, dtype=torch.float64, device=dev)
+    n_grt = torch.empty(C_, dtype=torch.int32, device=dev)
+    nbytes = load().dg_voc_ap_workspace_bytes(n, C_, I)
+    ws = workspace(dev, nbytes)
+    with torch.cuda.device(dev):
+        check(load().dg_voc_ap_f32(ptr(dimg), ptr(dbox), ptr(order), ptr(cls_off), n, ptr(timg), ptr(tcls), ptr(tbox),
+                                   timg.shape[0], C_, I, float(iou_thr), ptr(out), ptr(n_grt), ptr(ws), nbytes, stream_ptr(dev)))
+    return out, n_grt
+
+
 # ------------------------------------------------------------------ RoI pooling
 def roi_windows(rois, roi_idx, B, H, W, dev):
     r = _abi.to_dev(rois, torch.float64, dev).reshape(-1, 4)

@@ -148,44 +148,54 @@ def evaluate_batch(output, target, num_classes=5, prob_threshold=0.005, nms_thre
     return detects, targets
 
 
-def ap(detects, targets, iou_threds=0.01):
-    """VOC-style AP (yolo.py:306-367).  All detection-vs-GT IoUs of a class are computed in one
-    elementwise-IoU launch; the greedy TP/FP matching and the PR envelope stay on the host as in
-    the reference.  Like the reference, an empty class appends 0.0 and then still appends its AP."""
+def evaluate_batch_device(output, target, num_classes=5, prob_threshold=0.005, nms_threshold=0.3, image_offset=0):
+    """The rows evaluate_batch appends, left on the device as flat tensors in the reference's list order (image
+    ascending, then NMS rank): (det_img int32, det_cls int64, det_conf fp32, det_box (n,4) fp32, tgt_img int32,
+    tgt_cls int32, tgt_box (B,4) float64).  No host round trip; feed several batches' results, concatenated, to ap_device."""
+    box, label, conf, score, count, keep, kcnt, tbox, tlabel = decode_nms_batched(
+        output, target, 0.2, prob_threshold, nms_threshold)
+    B, N = keep.shape
+    dev = keep.device
+    sel = torch.arange(N, device=dev)[None, :] < kcnt[:, None]
+    img = torch.arange(B, device=dev)[:, None].expand(B, N)[sel]
+    idx = keep[sel]
+    return ((img + image_offset).to(torch.int32), label[img, idx], conf[img, idx], box[img, idx],
+            torch.arange(image_offset, image_offset + B, device=dev, dtype=torch.int32), (tlabel - 1).to(torch.int32), tbox)
+
+
+def ap_device(det_img, det_cls, det_conf, det_box, tgt_img, tgt_cls, tgt_box, num_classes, num_images, iou_threds=0.01):
+    """ap() on flat device arrays (evaluate_batch_device's layout): the same list the reference returns."""
+    out, n_grt = ops.voc_ap(det_img, det_cls, det_conf, det_box, tgt_img, tgt_cls, tgt_box, num_classes, num_images,
+                            np.float32(iou_threds))
+    out, n_grt = out.cpu().numpy(), n_grt.cpu().numpy()
     aps = []
-    for c in targets.keys():
-        if len(targets[c]) == 0:
+    for i in range(int(num_classes)):
+        if n_grt[i] == 0:
             aps.append(0.0)
-        n_grt = len(targets[c])
-        grts = {i[0]: i[2:] for i in targets[c]}
-        hit = {k: 0 for k in grts}
-        det = sorted(list(detects[c]), key=lambda x: x[1], reverse=True)
-        TP, FP = np.zeros(len(det)), np.zeros(len(det))
-        has = [d[0] in grts for d in det]
-        ious = np.full(len(det), -np.inf)
-        if any(has):
-            db = torch.tensor([d[2:] for d, h in zip(det, has) if h], dtype=torch.float32)
-            gb = torch.tensor([grts[d[0]] for d, h in zip(det, has) if h], dtype=torch.float32)
-            ious[np.array(has)] = get_iou(db, gb).numpy()
-        for d in range(len(det)):
-            if ious[d] >= iou_threds:
-                if hit[det[d][0]] == 0:
-                    TP[d] = 1
-                    hit[det[d][0]] = 1
-                else:
-                    FP[d] = 1
-            else:
-                FP[d] = 1
-        tp_sum, fp_sum = np.cumsum(TP), np.cumsum(FP)
-        with np.errstate(all="ignore"):
-            recall = tp_sum / n_grt
-            prec = np.divide(tp_sum, tp_sum + fp_sum)
-        recall = np.concatenate(([0.0], recall, [1.0]))
-        prec = np.concatenate(([0.0], prec, [0.0]))
-        for i in range(prec.size - 1, 0, -1):
-            prec[i - 1] = max(prec[i - 1], prec[i])
-        a = 0.0
-        for i in range(prec.size - 1):
-            a += (recall[i + 1] - recall[i]) * prec[i + 1]
-        aps.append(a)
+        aps.append(float(out[i]))
+    return aps
+
+
+def ap(detects, targets, iou_threds=0.01):
+    """VOC-style AP (yolo.py:306-367) for the reference's dict-of-row-lists.  The rows are flattened in list order
+    and handed to the device (ops.voc_ap: ordering, IoU vs the image's ground truth, first-hit matching, cumulative
+    sums, precision envelope and the area sum all run there); the host only rebuilds the list.  Like the reference,
+    an empty class appends 0.0 and then still appends its AP (:314-315)."""
+    keys = list(targets.keys())
+    pos = {k: i for i, k in enumerate(keys)}
+    det_rows = [(pos[c], r) for c in keys for r in detects[c]]
+    tgt_rows = [(pos[c], r) for c in keys for r in targets[c]]
+    images = sorted({r[0] for _, r in det_rows} | {r[0] for _, r in tgt_rows})
+    img_id = {v: i for i, v in enumerate(images)}           # any hashable image key, as in the reference's dict
+    d = np.array([[c, img_id[r[0]]] + [float(v) for v in r[1:6]] for c, r in det_rows], np.float64).reshape(-1, 7)
+    t = np.array([[c, img_id[r[0]]] + [float(v) for v in r[2:6]] for c, r in tgt_rows], np.float64).reshape(-1, 6)
+    out, n_grt = ops.voc_ap(d[:, 1].astype(np.int32), d[:, 0].astype(np.int64), d[:, 2], d[:, 3:7].astype(np.float32),
+                            t[:, 1].astype(np.int32), t[:, 0].astype(np.int32), t[:, 2:6].astype(np.float32),
+                            max(len(keys), 1), len(images), np.float32(iou_threds))
+    out, n_grt = out.cpu().numpy(), n_grt.cpu().numpy()
+    aps = []
+    for i in range(len(keys)):
+        if n_grt[i] == 0:
+            aps.append(0.0)
+        aps.append(float(out[i]))
     return aps
