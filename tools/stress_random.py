@@ -71,6 +71,14 @@ for it in range(rounds):
     ol, ocomp, ograd = oracle.yolo1_loss(out, tgt, quirk=True)
     loss6, grad = ops.yolo1_loss(torch.from_numpy(out).cuda(), torch.from_numpy(tgt).cuda(), True)
     chk("loss", abs(loss6[0].item() - ol) <= 3e-7 * abs(ol) and np.allclose(grad.cpu().numpy(), ograd, rtol=3e-6, atol=1e-7), (bs, Cn))
+    # ---- VOC AP: random detections / targets, thresholds incl. one that sits exactly on an occurring IoU
+    import tests.test_gpu_parity as T
+    from vision_amd import yolo_v1
+    det, tg = T._ap_case(int(rng.integers(1 << 30)), int(rng.integers(1, 400)), int(rng.integers(1, 8)), int(rng.integers(0, 12)),
+                         empty_classes=(0,) if rng.random() < 0.3 else ())
+    for thr in (0.05, 0.5, float(rng.uniform(0.01, 0.9))):
+        got, want = yolo_v1.ap(det, tg, thr), oracle.average_precision(det, tg, thr)
+        chk("ap", len(got) == len(want) and np.array_equal(np.array(got), np.array(want, np.float64), equal_nan=True), thr)
     print(f"round {it}: failures {len(fail)}  ({time.time() - t0:.0f} s)", flush=True)
 print("TOTAL FAILURES", len(fail), fail[:10])
 sys.exit(1 if fail else 0)
