@@ -376,6 +376,52 @@ __device__ __forceinline__ void roi_task_avg(char *smem, const char *__restrict_
     }
 }
 
+// One adaptive max bin straight from the map (any crop size): lane = channel, `base` points at this lane's channel of
+// the image.  First maximum in row-major order; with NANSAFE a NaN always wins (ATen).  Index = y*W + x.
+template <bool NANSAFE>
+__device__ __forceinline__ void direct_max_bin(const float *__restrict__ base, int W, int C, int hs, int he, int ws, int we,
+                                               float &best, int &bi)
+{
+    best = -INFINITY;
+    bi = hs * W + ws;
+    if (we - ws > 4) {
+        // wide bins (crops over ~28 columns): 8 loads in flight per batch
+        for (int y = hs; y < he; ++y) {
+            const float *row = base + (int64_t)y * W * C;
+            for (int x = ws; x < we; x += 8) {
+                int xs[8];
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) xs[q] = min(x + q, we - 1);      // past the end: clamped re-reads
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v[q] = row[(int64_t)xs[q] * C];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) max_upd<NANSAFE>(best, bi, v[q], y * W + xs[q]);
+            }
+        }
+    } else {
+        // bins of at most 4 columns: two rows (8 loads) in flight; past the bin's end or the last
+        // row: clamped re-reads (idempotent: a repeat can never win the strict compare)
+        const int xb = min(ws + 1, we - 1), xc = min(ws + 2, we - 1), xd = min(ws + 3, we - 1);
+        for (int y = hs; y < he; y += 2) {
+            const int y2r = min(y + 1, he - 1);
+            const float *row = base + (int64_t)y * W * C, *row2 = base + (int64_t)y2r * W * C;
+            const float va = row[(int64_t)ws * C], vb = row[(int64_t)xb * C];
+            const float vc = row[(int64_t)xc * C], vd = row[(int64_t)xd * C];
+            const float ua = row2[(int64_t)ws * C], ub = row2[(int64_t)xb * C];
+            const float uc = row2[(int64_t)xc * C], ud = row2[(int64_t)xd * C];
+            max_upd<NANSAFE>(best, bi, va, y * W + ws);
+            max_upd<NANSAFE>(best, bi, vb, y * W + xb);
+            max_upd<NANSAFE>(best, bi, vc, y * W + xc);
+            max_upd<NANSAFE>(best, bi, vd, y * W + xd);
+            max_upd<NANSAFE>(best, bi, ua, y2r * W + ws);
+            max_upd<NANSAFE>(best, bi, ub, y2r * W + xb);
+            max_upd<NANSAFE>(best, bi, uc, y2r * W + xc);
+            max_upd<NANSAFE>(best, bi, ud, y2r * W + xd);
+        }
+    }
+}
+
 template <int MODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_roipool_fwd(const float *__restrict__ nhwc, int C, int H, int W,
                                                     const int32_t *__restrict__ win, int cblocks, int64_t ntasks,
@@ -554,44 +600,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 for (int pw = 0; pw < RP; ++pw) {
                     const int ws = x1 + (pw * Lw) / RP, we = x1 + ((pw + 1) * Lw + RP - 1) / RP;
                     if (MODE == DG_POOL_MAX) {
-                        float best = -INFINITY;
-                        int bi = hs * W + ws;
-                        if (we - ws > 4) {
-                            // wide bins (crops over ~28 columns): 8 loads in flight per batch
-                            for (int y = hs; y < he; ++y) {
-                                const float *row = base + (int64_t)y * W * C;
-                                for (int x = ws; x < we; x += 8) {
-                                    int xs[8];
-                                    float v[8];
-#pragma unroll
-                                    for (int q = 0; q < 8; ++q) xs[q] = min(x + q, we - 1);      // past the end: clamped re-reads
-#pragma unroll
-                                    for (int q = 0; q < 8; ++q) v[q] = row[(int64_t)xs[q] * C];
-#pragma unroll
-                                    for (int q = 0; q < 8; ++q) max_upd<true>(best, bi, v[q], y * W + xs[q]);
-                                }
-                            }
-                        } else {
-                            // bins of at most 4 columns: two rows (8 loads) in flight; past the bin's end or the last
-                            // row: clamped re-reads (idempotent: a repeat can never win the strict compare)
-                            const int xb = min(ws + 1, we - 1), xc = min(ws + 2, we - 1), xd = min(ws + 3, we - 1);
-                            for (int y = hs; y < he; y += 2) {
-                                const int y2r = min(y + 1, he - 1);
-                                const float *row = base + (int64_t)y * W * C, *row2 = base + (int64_t)y2r * W * C;
-                                const float va = row[(int64_t)ws * C], vb = row[(int64_t)xb * C];
-                                const float vc = row[(int64_t)xc * C], vd = row[(int64_t)xd * C];
-                                const float ua = row2[(int64_t)ws * C], ub = row2[(int64_t)xb * C];
-                                const float uc = row2[(int64_t)xc * C], ud = row2[(int64_t)xd * C];
-                                max_upd<true>(best, bi, va, y * W + ws);
-                                max_upd<true>(best, bi, vb, y * W + xb);
-                                max_upd<true>(best, bi, vc, y * W + xc);
-                                max_upd<true>(best, bi, vd, y * W + xd);
-                                max_upd<true>(best, bi, ua, y2r * W + ws);
-                                max_upd<true>(best, bi, ub, y2r * W + xb);
-                                max_upd<true>(best, bi, uc, y2r * W + xc);
-                                max_upd<true>(best, bi, ud, y2r * W + xd);
-                            }
-                        }
+                        float best;
+                        int bi;
+                        if (may_nan) direct_max_bin<true>(base, W, C, hs, he, ws, we, best, bi);
+                        else direct_max_bin<false>(base, W, C, hs, he, ws, we, best, bi);
                         sval[lane * RBINS + ph * RP + pw] = best;
                         sidx[lane * RBINS + ph * RP + pw] = (unsigned short)bi;
                     } else {
