@@ -792,7 +792,6 @@ __global__ __launch_bounds__(NT) void k_roipool_bwd(const float *__restrict__ gr
         __shared__ float share[NT / 64][16 * 64];                 // [wave][channel (<= 16)][bin]
         __shared__ unsigned char binlo[NT / 64][2][64], binhi[NT / 64][2][64];   // [wave][axis][coordinate]
         const int lane = tid & 63, wave = tid >> 6;
-        const int ly = lane >> 3, lx = lane & 7;
         // software pipeline over the wave's RoIs: the RoI index is fetched two ahead, window and bin gradients one ahead
         const int nr = r1 - r0;
         int rr = wave;
@@ -841,10 +840,15 @@ __global__ __launch_bounds__(NT) void k_roipool_bwd(const float *__restrict__ gr
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
             float *pl = plane + y1 * W + x1;
-            for (int ty = 0; ty < Lh; ty += 8) {
-                for (int tx = 0; tx < Lw; tx += 8) {
-                    const int ry = ty + ly, rx = tx + lx;
-                    if (ry < Lh && rx < Lw) {
+            // lanes cover whole crop rows: 64 / Lw rows per pass (a 9-wide crop keeps 63 lanes busy; fixed 8x8 tiles kept
+            // 81 of 256).  Crops wider than 64 cells walk 64-cell row segments.
+            const int rpp = Lw <= 64 ? 64 / Lw : 1;                      // rows per pass
+            const int lyy = Lw <= 64 ? lane / Lw : 0, lxx = Lw <= 64 ? lane - lyy * Lw : lane;
+            const bool lane_on = Lw <= 64 ? lyy < rpp : true;
+            for (int ty = 0; ty < Lh; ty += rpp) {
+                for (int tx = 0; tx < Lw; tx += 64) {
+                    const int ry = ty + lyy, rx = tx + lxx;
+                    if (lane_on && ry < Lh && rx < Lw) {
                         int ph0, ph1, pw0, pw1;
                         if (small) { ph0 = binlo[wave][0][ry]; ph1 = binhi[wave][0][ry]; pw0 = binlo[wave][1][rx]; pw1 = binhi[wave][1][rx]; }
                         else { ph0 = (ry * RP) / Lh; ph1 = ((ry + 1) * RP + Lh - 1) / Lh - 1; pw0 = (rx * RP) / Lw; pw1 = ((rx + 1) * RP + Lw - 1) / Lw - 1; }
