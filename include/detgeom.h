@@ -132,7 +132,8 @@ int dg_kmeans_iou_step(const float *wh, int64_t n, const float *cent, int64_t k,
  * history (may be NULL): history[slot] = acc[3k] (changed count of this iteration). */
 int dg_kmeans_update(const int64_t *acc, int64_t k, float *cent, int64_t *history, int64_t slot, dg_stream_t s);
 /* `iters` iterations of step+update back to back on ONE device (no all-reduce), one launch per iteration:
- * history[slot0+t] = changed count. */
+ * history[slot0+t] = changed count.  acc is left as the LAST iteration wrote it; only that iteration forms the
+ * inertia sum acc[3k+1] (a Lloyd iteration does not need it), the earlier ones write 0 there. */
 int dg_kmeans_iou_run(const float *wh, int64_t n, float *cent, int64_t k, uint8_t *labels, int64_t *acc,
                       int64_t *history, int64_t slot0, int64_t iters, void *ws, size_t ws_bytes, dg_stream_t s);
 int dg_kmeans_labels_i32(const uint8_t *labels, int64_t n, int32_t *out, dg_stream_t s);

@@ -98,30 +98,33 @@ __device__ __forceinline__ unsigned long long fx32_biased(float v)
     return (unsigned long long)fx32(v) + KM_MAGIC;
 }
 
-template <bool FAST>
+template <bool FAST, bool INERTIA = true>
 __device__ __forceinline__ void km_accum(float w, float h, float bd, int best, unsigned long long *sacc, unsigned *scnt,
                                          unsigned long long &inertia, int &changed, uint8_t *lab)
 {
     atomicAdd(&sacc[(best * 2 + 0) * KM_BLOCK], fx32_biased<FAST>(w));
     atomicAdd(&sacc[(best * 2 + 1) * KM_BLOCK], fx32_biased<FAST>(h));
     atomicAdd(&scnt[best * KM_BLOCK], 1u);
-    inertia += fx32_biased<FAST>(bd);
+    if (INERTIA) inertia += fx32_biased<FAST>(bd);
     changed += (*lab != (uint8_t)best);
     *lab = (uint8_t)best;
 }
 
-template <int KMAX, bool FULL>
+template <int KMAX, bool FULL, bool INERTIA = true>
 __device__ __forceinline__ void km_one(float w, float h, const float (&cw)[KMAX], const float (&ch)[KMAX], int k,
                                        unsigned long long *sacc, unsigned *scnt, unsigned long long &inertia, int &changed,
                                        uint8_t *lab)
 {
     float bd;
     const int best = km_assign<KMAX, FULL>(w, h, cw, ch, k, bd);
-    if ((fabsf(w) + fabsf(h)) + fabsf(bd) < KM_FAST_LIMIT) km_accum<true>(w, h, bd, best, sacc, scnt, inertia, changed, lab);
-    else km_accum<false>(w, h, bd, best, sacc, scnt, inertia, changed, lab);
+    if ((fabsf(w) + fabsf(h)) + fabsf(bd) < KM_FAST_LIMIT) km_accum<true, INERTIA>(w, h, bd, best, sacc, scnt, inertia, changed, lab);
+    else km_accum<false, INERTIA>(w, h, bd, best, sacc, scnt, inertia, changed, lab);
 }
 
-template <int KMAX, bool FULL>
+// INERTIA = false (the iterations of dg_kmeans_iou_run before its last): the sum of distances is not formed, so the
+// winner's exact distance is not evaluated either; acc[3k+1] is then written as 0.  A Lloyd iteration needs the sums,
+// the counts and the changed count; the inertia is reported for the final assignment only (as sklearn does).
+template <int KMAX, bool FULL, bool INERTIA>
 __global__ __launch_bounds__(KM_BLOCK) void k_kmeans_step(const float2 *__restrict__ wh, int64_t n, const float *cent, int k,
                                                           uint8_t *__restrict__ labels, long long *partials, unsigned *ticket,
                                                           long long *__restrict__ acc, float *cent_out, long long *__restrict__ history,
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(KM_BLOCK) void k_kmeans_step(const float2 *__restri
     const int head = ((reinterpret_cast<uintptr_t>(wh) & 8) && n > 0) ? 1 : 0;
     if (head && blockIdx.x == 0 && tid == 0) {
         const float2 t = wh[0];
-        km_one<KMAX, FULL>(t.x, t.y, cw, ch, k, sacc, scnt, inertia, changed, labels);
+        km_one<KMAX, FULL, INERTIA>(t.x, t.y, cw, ch, k, sacc, scnt, inertia, changed, labels);
     }
     wh += head; n -= head;
     const int64_t npair = n >> 1;
@@ -179,9 +182,13 @@ __global__ __launch_bounds__(KM_BLOCK) void k_kmeans_step(const float2 *__restri
         const bool f0 = km_filter<KMAX, FULL>(a.x, a.y, cw, ch, k, gap_min, b0), f1 = km_filter<KMAX, FULL>(a.z, a.w, cw, ch, k, gap_min, b1);
         const bool f2 = km_filter<KMAX, FULL>(b.x, b.y, cw, ch, k, gap_min, b2), f3 = km_filter<KMAX, FULL>(b.z, b.w, cw, ch, k, gap_min, b3);
         if ((f0 && f1) && (f2 && f3) && magwh < KM_FAST_LIMIT) {
-            const float2 c0 = scent[b0], c1 = scent[b1], c2 = scent[b2], c3 = scent[b3];
-            d0 = kdist(a.x, a.y, c0.x, c0.y); d1 = kdist(a.z, a.w, c1.x, c1.y);
-            d2 = kdist(b.x, b.y, c2.x, c2.y); d3 = kdist(b.z, b.w, c3.x, c3.y);
+            if (INERTIA) {
+                const float2 c0 = scent[b0], c1 = scent[b1], c2 = scent[b2], c3 = scent[b3];
+                d0 = kdist(a.x, a.y, c0.x, c0.y); d1 = kdist(a.z, a.w, c1.x, c1.y);
+                d2 = kdist(b.x, b.y, c2.x, c2.y); d3 = kdist(b.z, b.w, c3.x, c3.y);
+            } else {
+                d0 = d1 = d2 = d3 = 0.f;
+            }
         } else {
             b0 = km_assign<KMAX, FULL>(a.x, a.y, cw, ch, k, d0); b1 = km_assign<KMAX, FULL>(a.z, a.w, cw, ch, k, d1);
             b2 = km_assign<KMAX, FULL>(b.x, b.y, cw, ch, k, d2); b3 = km_assign<KMAX, FULL>(b.z, b.w, cw, ch, k, d3);
@@ -189,26 +196,45 @@ __global__ __launch_bounds__(KM_BLOCK) void k_kmeans_step(const float2 *__restri
         // one range test for the four boxes: every term is >= 0, so a sum below the limit bounds each of them
         const float mag = magwh + ((fabsf(d0) + fabsf(d1)) + (fabsf(d2) + fabsf(d3)));
         if (mag < KM_FAST_LIMIT) {
-            km_accum<true>(a.x, a.y, d0, b0, sacc, scnt, inertia, changed, lab + 2 * i);
-            km_accum<true>(a.z, a.w, d1, b1, sacc, scnt, inertia, changed, lab + 2 * i + 1);
-            km_accum<true>(b.x, b.y, d2, b2, sacc, scnt, inertia, changed, lab + 2 * (i + stride));
-            km_accum<true>(b.z, b.w, d3, b3, sacc, scnt, inertia, changed, lab + 2 * (i + stride) + 1);
+            km_accum<true, INERTIA>(a.x, a.y, d0, b0, sacc, scnt, inertia, changed, lab + 2 * i);
+            km_accum<true, INERTIA>(a.z, a.w, d1, b1, sacc, scnt, inertia, changed, lab + 2 * i + 1);
+            km_accum<true, INERTIA>(b.x, b.y, d2, b2, sacc, scnt, inertia, changed, lab + 2 * (i + stride));
+            km_accum<true, INERTIA>(b.z, b.w, d3, b3, sacc, scnt, inertia, changed, lab + 2 * (i + stride) + 1);
         } else {
-            km_accum<false>(a.x, a.y, d0, b0, sacc, scnt, inertia, changed, lab + 2 * i);
-            km_accum<false>(a.z, a.w, d1, b1, sacc, scnt, inertia, changed, lab + 2 * i + 1);
-            km_accum<false>(b.x, b.y, d2, b2, sacc, scnt, inertia, changed, lab + 2 * (i + stride));
-            km_accum<false>(b.z, b.w, d3, b3, sacc, scnt, inertia, changed, lab + 2 * (i + stride) + 1);
+            km_accum<false, INERTIA>(a.x, a.y, d0, b0, sacc, scnt, inertia, changed, lab + 2 * i);
+            km_accum<false, INERTIA>(a.z, a.w, d1, b1, sacc, scnt, inertia, changed, lab + 2 * i + 1);
+            km_accum<false, INERTIA>(b.x, b.y, d2, b2, sacc, scnt, inertia, changed, lab + 2 * (i + stride));
+            km_accum<false, INERTIA>(b.z, b.w, d3, b3, sacc, scnt, inertia, changed, lab + 2 * (i + stride) + 1);
         }
         i = inext; a = na; b = nb; have = more;
     }
-    for (; i < npair; i += stride) {
+    for (; i < npair; i += stride) {                     // what the four-box loop leaves: same scheme, two boxes
         const float4 t = wh4[i];
-        km_one<KMAX, FULL>(t.x, t.y, cw, ch, k, sacc, scnt, inertia, changed, lab + 2 * i);
-        km_one<KMAX, FULL>(t.z, t.w, cw, ch, k, sacc, scnt, inertia, changed, lab + 2 * i + 1);
+        float d0, d1;
+        int b0, b1;
+        const float magwh = (fabsf(t.x) + fabsf(t.y)) + (fabsf(t.z) + fabsf(t.w));
+        const bool f0 = km_filter<KMAX, FULL>(t.x, t.y, cw, ch, k, gap_min, b0), f1 = km_filter<KMAX, FULL>(t.z, t.w, cw, ch, k, gap_min, b1);
+        if (f0 && f1 && magwh < KM_FAST_LIMIT) {
+            if (INERTIA) {
+                const float2 c0 = scent[b0], c1 = scent[b1];
+                d0 = kdist(t.x, t.y, c0.x, c0.y); d1 = kdist(t.z, t.w, c1.x, c1.y);
+            } else {
+                d0 = d1 = 0.f;
+            }
+        } else {
+            b0 = km_assign<KMAX, FULL>(t.x, t.y, cw, ch, k, d0); b1 = km_assign<KMAX, FULL>(t.z, t.w, cw, ch, k, d1);
+        }
+        if (magwh + (fabsf(d0) + fabsf(d1)) < KM_FAST_LIMIT) {
+            km_accum<true, INERTIA>(t.x, t.y, d0, b0, sacc, scnt, inertia, changed, lab + 2 * i);
+            km_accum<true, INERTIA>(t.z, t.w, d1, b1, sacc, scnt, inertia, changed, lab + 2 * i + 1);
+        } else {
+            km_accum<false, INERTIA>(t.x, t.y, d0, b0, sacc, scnt, inertia, changed, lab + 2 * i);
+            km_accum<false, INERTIA>(t.z, t.w, d1, b1, sacc, scnt, inertia, changed, lab + 2 * i + 1);
+        }
     }
     if ((n & 1) && blockIdx.x == 0 && tid == 0) {
         const float2 t = wh[n - 1];
-        km_one<KMAX, FULL>(t.x, t.y, cw, ch, k, sacc, scnt, inertia, changed, lab + (n - 1));
+        km_one<KMAX, FULL, INERTIA>(t.x, t.y, cw, ch, k, sacc, scnt, inertia, changed, lab + (n - 1));
     }
 
     // block reduction: wave shuffles, then LDS across the 4 waves
@@ -224,7 +250,7 @@ __global__ __launch_bounds__(KM_BLOCK) void k_kmeans_step(const float2 *__restri
     }
     {
         long long a = wave_sum_ll((long long)changed), b2 = wave_sum_ll((long long)inertia);
-        if (lane == 0) { red[wave][3 * KMAX] = a; red[wave][3 * KMAX + 1] = b2 - (long long)((unsigned long long)nbox * KM_MAGIC); }
+        if (lane == 0) { red[wave][3 * KMAX] = a; red[wave][3 * KMAX + 1] = INERTIA ? b2 - (long long)((unsigned long long)nbox * KM_MAGIC) : 0; }
     }
     __syncthreads();
     if (tid < CP) {
@@ -336,7 +362,9 @@ static int km_resident_blocks(K kernel)
 }
 static inline int km_blocks(int64_t n, int resident)
 {
-    int64_t b = dg_cdiv(n, KM_BLOCK * 4);
+    // at least 16 boxes per thread: a small shard (1.25 M boxes) runs 16 us with 305 workgroups and 26 us with 1024,
+    // whose prologues and partial rows (folded by the last workgroup) then outweigh the boxes
+    int64_t b = dg_cdiv(n, KM_BLOCK * 16);
     return (int)(b < 1 ? 1 : (b > resident ? resident : b));
 }
 
@@ -349,16 +377,21 @@ static inline unsigned *km_ticket(void *ws) { return (unsigned *)((char *)ws + (
 
 // step (+ fold) as one launch; with cent_out the last workgroup also writes the new centroids and history[slot]
 static int km_launch(const float *wh, int64_t n, const float *cent, int64_t k, uint8_t *labels, int64_t *acc, float *cent_out,
-                     int64_t *history, int64_t slot, void *ws, hipStream_t st)
+                     int64_t *history, int64_t slot, bool inertia, void *ws, hipStream_t st)
 {
     const int kmax = km_kmax(k);
     long long *partials = (long long *)ws;
+#define KM_LAUNCH1(KM, FULL, INERTIA)                                                                                           \
+    do {                                                                                                                        \
+        static const int resident = km_resident_blocks(k_kmeans_step<KM, FULL, INERTIA>);                                       \
+        hipLaunchKernelGGL((k_kmeans_step<KM, FULL, INERTIA>), dim3(km_blocks(n, resident)), dim3(KM_BLOCK), 0, st,             \
+                           (const float2 *)wh, n, cent, (int)k, labels, partials, km_ticket(ws), (long long *)acc, cent_out,    \
+                           (long long *)history, slot);                                                                         \
+    } while (0)
 #define KM_LAUNCH(KM, FULL)                                                                                                     \
     do {                                                                                                                        \
-        static const int resident = km_resident_blocks(k_kmeans_step<KM, FULL>);                                                \
-        hipLaunchKernelGGL((k_kmeans_step<KM, FULL>), dim3(km_blocks(n, resident)), dim3(KM_BLOCK), 0, st, (const float2 *)wh,  \
-                           n, cent, (int)k, labels, partials, km_ticket(ws), (long long *)acc, cent_out, (long long *)history,  \
-                           slot);                                                                                               \
+        if (inertia) KM_LAUNCH1(KM, FULL, true);                                                                                \
+        else KM_LAUNCH1(KM, FULL, false);                                                                                       \
     } while (0)
     // k == 5 and k == 9 (the YOLOv2 anchor counts) get kernels without the per-cluster `c < k` branches
     if (k == 5) KM_LAUNCH(5, true);
@@ -367,6 +400,7 @@ static int km_launch(const float *wh, int64_t n, const float *cent, int64_t k, u
     else if (kmax == 9) KM_LAUNCH(9, false);
     else KM_LAUNCH(16, false);
 #undef KM_LAUNCH
+#undef KM_LAUNCH1
     DG_CHECK_LAUNCH("k_kmeans_step");
     return DG_OK;
 }
@@ -390,7 +424,7 @@ extern "C" int dg_kmeans_iou_step(const float *wh, int64_t n, const float *cent,
     hipStream_t st = (hipStream_t)s;
     // the workspace arrives with arbitrary contents
     if (hipMemsetAsync(km_ticket(ws), 0, 16, st) != hipSuccess) { dg_set_error("kmeans_step: memset failed"); return DG_EHIP; }
-    return km_launch(wh, n, cent, k, labels, acc, nullptr, nullptr, 0, ws, st);
+    return km_launch(wh, n, cent, k, labels, acc, nullptr, nullptr, 0, true, ws, st);
 }
 
 extern "C" int dg_kmeans_update(const int64_t *acc, int64_t k, float *cent, int64_t *history, int64_t slot, dg_stream_t s)
@@ -415,7 +449,7 @@ extern "C" int dg_kmeans_iou_run(const float *wh, int64_t n, float *cent, int64_
     hipStream_t st = (hipStream_t)s;
     if (hipMemsetAsync(km_ticket(ws), 0, 16, st) != hipSuccess) { dg_set_error("kmeans_run: memset failed"); return DG_EHIP; }
     for (int64_t t = 0; t < iters; ++t) {
-        rc = km_launch(wh, n, cent, k, labels, acc, cent, history, slot0 + t, ws, st);
+        rc = km_launch(wh, n, cent, k, labels, acc, cent, history, slot0 + t, t + 1 == iters, ws, st);   // inertia: last only
         if (rc) return rc;
     }
     return DG_OK;
