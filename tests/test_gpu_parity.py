@@ -525,6 +525,18 @@ def test_kmeans_vs_oracle(va, oracle, n, k):
     assert np.array_equal(km.predict(wh), labels)
 
 
+@pytest.mark.parametrize("iters", [1, 2, 7])
+def test_kmeans_fixed_iterations_vs_oracle(va, oracle, iters):
+    """the device-side loop stopped after a fixed number of iterations (the bench's mode): centroids, labels and the
+    inertia of the LAST iteration (the only one that forms it) equal the oracle's."""
+    from vision_amd import cluster
+    wh = wl.anchor_wh(11, 300001)
+    km = cluster.kmean(n_clusters=5, random_state=42).fit(wh, fixed_iters=iters)
+    cent, labels, n_iter, inertia = oracle.kmeans_fit(wh, 5, 42, fixed_iters=iters)
+    assert np.array_equal(km.labels_, labels) and np.array_equal(km.cluster_centers_, cent)
+    assert km.n_iter_ == iters and abs(km.inertia_ - inertia) < 1e-9
+
+
 def test_kmeans_sharded_equals_single(va, oracle):
     """fake all-reduce: shards stepped one after another on one device, integer partial sums added."""
     from vision_amd import ops
