@@ -538,7 +538,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                     switch (Lw) {
                     EXACT(1); EXACT(2); EXACT(3); EXACT(4); EXACT(5); EXACT(6); EXACT(7); EXACT(8);
                     EXACT(9); EXACT(10); EXACT(11); EXACT(12); EXACT(13); EXACT(14); EXACT(15); EXACT(16);
-                          
                     default:                           // 17..24 wide: generic code, 3 or 4 positions per bin
                         if (maxw <= 3) roi_task_staged<3, false>(smem, imgc0, C * 4, W, lane, x1, y1, x2, y2, R, oval, oidx STAMP_ARG);
                         else roi_task_staged<4, false>(smem, imgc0, C * 4, W, lane, x1, y1, x2, y2, R, oval, oidx STAMP_ARG);
