@@ -110,12 +110,22 @@ int dg_nchw_to_nhwc_f32(const float *src, int64_t B, int64_t C, int64_t H, int64
 int dg_roipool_fwd_f32(const float *img_nhwc, int64_t B, int64_t C, int64_t H, int64_t W,
                        const int32_t *win, int64_t n, int64_t P, int mode, const int32_t *nan_flag,
                        float *out, int32_t *argmax, dg_stream_t s);
+/* The same forward with the argmax written as uint16 (H*W <= 65535 is a precondition of the forward anyway): half the
+ * index bytes to write here and to read in the backward.  The reference has no argmax tensor (autograd keeps its own
+ * indices), so its width is this build's choice; the int32 entry points above stay for callers that want one. */
+int dg_roipool_fwd_a16_f32(const float *img_nhwc, int64_t B, int64_t C, int64_t H, int64_t W,
+                           const int32_t *win, int64_t n, int64_t P, int mode, const int32_t *nan_flag,
+                           float *out, uint16_t *argmax16, dg_stream_t s);
 /* R2 backward (autograd in the reference).  grad_out (n,C,P,P), argmax from the forward (max mode);
  * grad_in (B,C,H,W) is overwritten (not accumulated).  Workspace holds the per-image RoI lists. */
 size_t dg_roipool_bwd_workspace_bytes(int64_t B, int64_t n);
 int dg_roipool_bwd_f32(const float *grad_out, const int32_t *argmax, const int32_t *win, int64_t n,
                        int64_t B, int64_t C, int64_t H, int64_t W, int64_t P, int mode, float *grad_in,
                        void *ws, size_t ws_bytes, dg_stream_t s);
+/* backward from a uint16 argmax (dg_roipool_fwd_a16_f32); otherwise as dg_roipool_bwd_f32 */
+int dg_roipool_bwd_a16_f32(const float *grad_out, const uint16_t *argmax16, const int32_t *win, int64_t n,
+                           int64_t B, int64_t C, int64_t H, int64_t W, int64_t P, int mode, float *grad_in,
+                           void *ws, size_t ws_bytes, dg_stream_t s);
 
 /* ---------------------------------------------------------------- anchor k-means (1-IoU)
  * K1: the reference only fixes the sklearn-style API (clustering/cluster_prac.py:38-40); the 1-IoU

@@ -512,6 +512,27 @@ def test_label_proposals_golden(va, golden):
     assert np.array_equal(rois, g["frcnn_rois"]) and np.array_equal(labels, g["frcnn_labels"])
 
 
+@pytest.mark.parametrize("C,n", [(512, 2000), (70, 300), (128, 1), (8, 50), (4, 50)])
+def test_roipool_uint16_argmax_equals_int32(va, C, n):
+    """the 16-bit argmax layout (vector and scalar store paths, partial channel blocks) holds the same indices, and the
+    backward from it gives the same gradient bits' worth of result as from the int32 one."""
+    from vision_amd import ops
+    rng = np.random.default_rng(C + n)
+    img = torch.from_numpy(rng.standard_normal((2, C, 38, 50), dtype=np.float32)).cuda()
+    rois = np.concatenate([wl.frcnn_rois(1, n), wl.frcnn_rois(2, n)])
+    rois[::7, 2:] = np.minimum(1.0, rois[::7, :2] + 0.7)                       # some wide crops (direct path)
+    idx = np.repeat(np.arange(2), n).astype(np.int64)
+    win, st = ops.roi_windows(rois, idx, 2, 38, 50, img.device)
+    out32, a32 = ops.roipool_forward(img, win, "max")
+    out16, a16 = ops.roipool_forward(img, win, "max", argmax_dtype=torch.int16)
+    assert a16.dtype == torch.int16 and torch.equal(out32, out16)
+    assert torch.equal(ops.argmax_i32(a16), a32)
+    g = torch.from_numpy(rng.standard_normal(tuple(out32.shape), dtype=np.float32)).cuda()
+    g32 = ops.roipool_backward(g, a32, win, img.shape, "max")
+    g16 = ops.roipool_backward(g, a16, win, img.shape, "max")
+    assert torch.allclose(g32, g16, rtol=1e-4, atol=1e-3)                       # LDS accumulation order is not fixed
+
+
 # ------------------------------------------------------------------ k-means
 @pytest.mark.parametrize("n,k", [(1000, 5), (200000, 5), (50000, 9)])
 def test_kmeans_vs_oracle(va, oracle, n, k):

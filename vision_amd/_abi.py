@@ -38,8 +38,10 @@ SIGNATURES = {
     "dg_roi_windows": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "dg_nchw_to_nhwc_f32": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "dg_roipool_fwd_f32": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, C.c_int, _vp, _vp, _vp, _vp]),
+    "dg_roipool_fwd_a16_f32": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, C.c_int, _vp, _vp, _vp, _vp]),
     "dg_roipool_bwd_workspace_bytes": (_sz, [_i64, _i64]),
     "dg_roipool_bwd_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, C.c_int, _vp, _vp, _sz, _vp]),
+    "dg_roipool_bwd_a16_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, C.c_int, _vp, _vp, _sz, _vp]),
     "dg_kmeans_workspace_bytes": (_sz, [_i64, _i64]),
     "dg_kmeans_iou_step": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
     "dg_kmeans_update": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp]),

@@ -426,8 +426,10 @@ template <int MODE>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_roipool_fwd(const float *__restrict__ nhwc, int C, int H, int W,
                                                     const int32_t *__restrict__ win, int cblocks, int64_t ntasks,
                                                     const int32_t *__restrict__ nan_flag,
-                                                    float *__restrict__ out, int32_t *__restrict__ argmax, int vec_ok)
+                                                    float *__restrict__ out, int32_t *__restrict__ argmax,
+                                                    unsigned short *__restrict__ argmax16, int vec_ok)
 {
+    // vec_ok: bit 0 = 16-byte stores of out / argmax, bit 1 = 16-byte stores of argmax16
     __shared__ __attribute__((aligned(16))) float smemf[FWD_LDS_FLOATS];
     float *sval = smemf;
     unsigned short *sidx = reinterpret_cast<unsigned short *>(smemf + 64 * RBINS);
@@ -464,7 +466,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         // contiguous run of cvalid*49 outputs for this (roi, channel block)
         const int64_t obase = (roi * C + c0) * RBINS;
         const int total = cvalid * RBINS;
-        if (vec_ok) {
+        if (vec_ok & 1) {
             // 64*49/4 = 784 16-byte pieces = 12.25 wave-wide rounds; reads of a batch are issued before its stores
             if (cvalid == 64) {
                 const float *sv = sval + lane * 4;
@@ -507,6 +509,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             for (int e = lane; e < total; e += 64) {
                 out[obase + e] = sval[e];
                 if (MODE == DG_POOL_MAX && argmax) argmax[obase + e] = sidx[e];
+            }
+        }
+        // 16-bit argmax (H*W <= 65535): the LDS image goes out as it is, 64*49/8 = 392 16-byte pieces = 6.125 rounds
+        if (MODE == DG_POOL_MAX && argmax16) {
+            if ((vec_ok & 2) && cvalid == 64) {
+                const unsigned short *si = sidx + lane * 8;
+                unsigned short *ga = argmax16 + obase + lane * 8;
+                int4 u[6];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) u[k] = *reinterpret_cast<const int4 *>(si + k * 512);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) nt_store4(reinterpret_cast<int32_t *>(ga + k * 512), u[k]);
+                if (lane < 8) nt_store4(reinterpret_cast<int32_t *>(ga + 6 * 512), *reinterpret_cast<const int4 *>(si + 6 * 512));
+            } else {
+                for (int e = lane; e < total; e += 64) argmax16[obase + e] = sidx[e];
             }
         }
         __syncthreads();      // the buffer is reused by the next task's ring
@@ -727,13 +744,20 @@ __device__ __forceinline__ void lds_fadd4(float *p, int stride, const float (&g)
 // grid: x = channel block (CB channels), y = image.  Dynamic LDS: CB*H*W floats.
 // VEC: CB*49 % 4 == 0 and 16-byte aligned tensors -> each thread moves 4 consecutive elements of one RoI
 // (16-byte loads of grad_out and argmax), two such groups in flight per thread.
-template <int MODE, bool VEC, int NT>
-__global__ __launch_bounds__(NT) void k_roipool_bwd(const float *__restrict__ grad_out, const int32_t *__restrict__ argmax,
+template <int MODE, bool VEC, int NT, bool A16>
+__global__ __launch_bounds__(NT) void k_roipool_bwd(const float *__restrict__ grad_out, const void *__restrict__ argmax_v,
                                                      const int32_t *__restrict__ win, const int32_t *__restrict__ off,
                                                      const int32_t *__restrict__ list, int C, int H, int W, int CB,
                                                      float *__restrict__ grad_in)
 {
     extern __shared__ __attribute__((aligned(16))) float plane[];
+    // argmax as the forward wrote it: int32, or uint16 (A16: half the index bytes; H*W <= 65535 always holds here)
+    const int32_t *argmax = reinterpret_cast<const int32_t *>(argmax_v);
+    const unsigned short *argmax16 = reinterpret_cast<const unsigned short *>(argmax_v);
+    auto idx4 = [&](int64_t o) {
+        if (A16) { const ushort4 u = *reinterpret_cast<const ushort4 *>(argmax16 + o); return make_int4(u.x, u.y, u.z, u.w); }
+        return *reinterpret_cast<const int4 *>(argmax + o);
+    };
     const int tid = threadIdx.x;
     const int b = blockIdx.y, c0 = blockIdx.x * CB;
     const int cb = (C - c0) < CB ? (C - c0) : CB;
@@ -757,9 +781,9 @@ __global__ __launch_bounds__(NT) void k_roipool_bwd(const float *__restrict__ gr
             const int64_t oa = ((int64_t)list[r0 + ra] * C + c0) * RBINS + 4 * qa;
             const int64_t ob = ((int64_t)list[r0 + rb] * C + c0) * RBINS + 4 * qb;
             const float4 ga = *reinterpret_cast<const float4 *>(grad_out + oa);
-            const int4 ia = *reinterpret_cast<const int4 *>(argmax + oa);
+            const int4 ia = idx4(oa);
             const float4 gb = *reinterpret_cast<const float4 *>(grad_out + ob);
-            const int4 ib = *reinterpret_cast<const int4 *>(argmax + ob);
+            const int4 ib = idx4(ob);
             const int ea = 4 * qa, eb = 4 * qb;
             lds_fadd(&plane[((ea + 0) / RBINS) * HW + ia.x], ga.x);
             lds_fadd(&plane[((ea + 1) / RBINS) * HW + ia.y], ga.y);
@@ -774,7 +798,7 @@ __global__ __launch_bounds__(NT) void k_roipool_bwd(const float *__restrict__ gr
             const int ra = (int)(t / per4), qa = (int)(t - (int64_t)ra * per4);
             const int64_t oa = ((int64_t)list[r0 + ra] * C + c0) * RBINS + 4 * qa;
             const float4 ga = *reinterpret_cast<const float4 *>(grad_out + oa);
-            const int4 ia = *reinterpret_cast<const int4 *>(argmax + oa);
+            const int4 ia = idx4(oa);
             const int ea = 4 * qa;
             lds_fadd(&plane[((ea + 0) / RBINS) * HW + ia.x], ga.x);
             lds_fadd(&plane[((ea + 1) / RBINS) * HW + ia.y], ga.y);
@@ -879,7 +903,7 @@ __global__ __launch_bounds__(NT) void k_roipool_bwd(const float *__restrict__ gr
             const int rr = (int)(t / per), e = (int)(t - (int64_t)rr * per);
             const int roi = list[r0 + rr];
             const int64_t o = ((int64_t)roi * C + c0) * RBINS + e;
-            lds_fadd(&plane[(e / RBINS) * HW + argmax[o]], grad_out[o]);
+            lds_fadd(&plane[(e / RBINS) * HW + (A16 ? (int)argmax16[o] : argmax[o])], grad_out[o]);
         }
     }
     __syncthreads();
@@ -916,9 +940,8 @@ extern "C" int dg_nchw_to_nhwc_f32(const float *src, int64_t B, int64_t C, int64
     return DG_OK;
 }
 
-extern "C" int dg_roipool_fwd_f32(const float *img_nhwc, int64_t B, int64_t C, int64_t H, int64_t W,
-                                  const int32_t *win, int64_t n, int64_t P, int mode, const int32_t *nan_flag,
-                                  float *out, int32_t *argmax, dg_stream_t s)
+static int roipool_fwd(const float *img_nhwc, int64_t B, int64_t C, int64_t H, int64_t W, const int32_t *win, int64_t n, int64_t P,
+                       int mode, const int32_t *nan_flag, float *out, int32_t *argmax, uint16_t *argmax16, dg_stream_t s)
 {
     DG_REQUIRE(n >= 0 && B > 0 && C > 0 && H > 0 && W > 0, "roipool_fwd: bad shape");
     DG_REQUIRE(P == RP, "roipool_fwd: only output_size 7 is built (got %lld)", (long long)P);
@@ -926,18 +949,34 @@ extern "C" int dg_roipool_fwd_f32(const float *img_nhwc, int64_t B, int64_t C, i
     DG_REQUIRE(H * W <= 65535, "roipool_fwd: H*W > 65535 unsupported (16-bit staged argmax)");
     if (n == 0) return DG_OK;
     DG_REQUIRE(img_nhwc && win && out, "roipool_fwd: null pointer");
-    int vec_ok = (C % 4 == 0) && ((((uintptr_t)out) & 15) == 0) && (!argmax || (((uintptr_t)argmax) & 15) == 0);
+    DG_REQUIRE((((uintptr_t)argmax16) & 1) == 0, "roipool_fwd: misaligned argmax16");
+    int vec_ok = ((C % 4 == 0) && ((((uintptr_t)out) & 15) == 0) && (!argmax || (((uintptr_t)argmax) & 15) == 0)) ? 1 : 0;
+    if (argmax16 && C % 8 == 0 && (((uintptr_t)argmax16) & 15) == 0) vec_ok |= 2;
     hipStream_t st = (hipStream_t)s;
     const int64_t cblocks = dg_cdiv(C, 64);
     const int64_t ntasks = n * cblocks;
     const int64_t maxgrid = 256 * 8;                   // 256 CUs x 8 resident single-wave workgroups (18.8 KB LDS each)
     dim3 grid((unsigned)(ntasks < maxgrid ? ntasks : maxgrid));
     if (mode == DG_POOL_MAX)
-        hipLaunchKernelGGL((k_roipool_fwd<DG_POOL_MAX>), grid, dim3(64), 0, st, img_nhwc, (int)C, (int)H, (int)W, win, (int)cblocks, ntasks, nan_flag, out, argmax, vec_ok);
+        hipLaunchKernelGGL((k_roipool_fwd<DG_POOL_MAX>), grid, dim3(64), 0, st, img_nhwc, (int)C, (int)H, (int)W, win, (int)cblocks, ntasks, nan_flag, out, argmax, argmax16, vec_ok);
     else
-        hipLaunchKernelGGL((k_roipool_fwd<DG_POOL_AVG>), grid, dim3(64), 0, st, img_nhwc, (int)C, (int)H, (int)W, win, (int)cblocks, ntasks, nan_flag, out, argmax, vec_ok);
+        hipLaunchKernelGGL((k_roipool_fwd<DG_POOL_AVG>), grid, dim3(64), 0, st, img_nhwc, (int)C, (int)H, (int)W, win, (int)cblocks, ntasks, nan_flag, out, argmax, argmax16, vec_ok);
     DG_CHECK_LAUNCH("k_roipool_fwd");
     return DG_OK;
+}
+
+extern "C" int dg_roipool_fwd_f32(const float *img_nhwc, int64_t B, int64_t C, int64_t H, int64_t W,
+                                  const int32_t *win, int64_t n, int64_t P, int mode, const int32_t *nan_flag,
+                                  float *out, int32_t *argmax, dg_stream_t s)
+{
+    return roipool_fwd(img_nhwc, B, C, H, W, win, n, P, mode, nan_flag, out, argmax, nullptr, s);
+}
+
+extern "C" int dg_roipool_fwd_a16_f32(const float *img_nhwc, int64_t B, int64_t C, int64_t H, int64_t W,
+                                      const int32_t *win, int64_t n, int64_t P, int mode, const int32_t *nan_flag,
+                                      float *out, uint16_t *argmax16, dg_stream_t s)
+{
+    return roipool_fwd(img_nhwc, B, C, H, W, win, n, P, mode, nan_flag, out, nullptr, argmax16, s);
 }
 
 struct BwdWs { int32_t *cnt, *off, *cursor, *list; size_t total; };
@@ -961,9 +1000,9 @@ extern "C" size_t dg_roipool_bwd_workspace_bytes(int64_t B, int64_t n)
     return bwd_layout(B, n, nullptr).total;
 }
 
-extern "C" int dg_roipool_bwd_f32(const float *grad_out, const int32_t *argmax, const int32_t *win, int64_t n,
-                                  int64_t B, int64_t C, int64_t H, int64_t W, int64_t P, int mode, float *grad_in,
-                                  void *ws, size_t ws_bytes, dg_stream_t s)
+static int roipool_bwd(const float *grad_out, const void *argmax, bool a16, const int32_t *win, int64_t n,
+                       int64_t B, int64_t C, int64_t H, int64_t W, int64_t P, int mode, float *grad_in,
+                       void *ws, size_t ws_bytes, dg_stream_t s)
 {
     DG_REQUIRE(n >= 0 && B > 0 && C > 0 && H > 0 && W > 0, "roipool_bwd: bad shape");
     DG_REQUIRE(P == RP, "roipool_bwd: only output_size 7 is built");
@@ -991,14 +1030,28 @@ extern "C" int dg_roipool_bwd_f32(const float *grad_out, const int32_t *argmax, 
     size_t lds = (size_t)CB * HW * 4;
     if (S > 1 && hipMemsetAsync(grad_in, 0, (size_t)B * C * HW * 4, st) != hipSuccess) { dg_set_error("roipool_bwd: memset failed"); return DG_EHIP; }
     // vector path: every channel slice is whole groups of 4 elements and 16-byte aligned
-    const bool vec = mode == DG_POOL_MAX && CB % 4 == 0 && C % CB == 0 &&
-                     ((((uintptr_t)grad_out) | ((uintptr_t)argmax)) & 15) == 0;
-    if (mode == DG_POOL_MAX && vec)
-        hipLaunchKernelGGL((k_roipool_bwd<DG_POOL_MAX, true, 256>), grid, dim3(256), lds, st, grad_out, argmax, win, w.off, w.list, (int)C, (int)H, (int)W, CB, grad_in);
-    else if (mode == DG_POOL_MAX)
-        hipLaunchKernelGGL((k_roipool_bwd<DG_POOL_MAX, false, 256>), grid, dim3(256), lds, st, grad_out, argmax, win, w.off, w.list, (int)C, (int)H, (int)W, CB, grad_in);
-    else
-        hipLaunchKernelGGL((k_roipool_bwd<DG_POOL_AVG, false, 512>), grid, dim3(512), lds, st, grad_out, argmax, win, w.off, w.list, (int)C, (int)H, (int)W, CB, grad_in);
+    const bool vec = mode == DG_POOL_MAX && CB % 4 == 0 && C % CB == 0 && (((uintptr_t)grad_out) & 15) == 0 &&
+                     (((uintptr_t)argmax) & (a16 ? 7 : 15)) == 0;
+#define BWD_LAUNCH(MODE, VEC, NT, A16) \
+    hipLaunchKernelGGL((k_roipool_bwd<MODE, VEC, NT, A16>), grid, dim3(NT), lds, st, grad_out, argmax, win, w.off, w.list, (int)C, (int)H, (int)W, CB, grad_in)
+    if (mode == DG_POOL_MAX && vec) { if (a16) BWD_LAUNCH(DG_POOL_MAX, true, 256, true); else BWD_LAUNCH(DG_POOL_MAX, true, 256, false); }
+    else if (mode == DG_POOL_MAX) { if (a16) BWD_LAUNCH(DG_POOL_MAX, false, 256, true); else BWD_LAUNCH(DG_POOL_MAX, false, 256, false); }
+    else BWD_LAUNCH(DG_POOL_AVG, false, 512, false);
+#undef BWD_LAUNCH
     DG_CHECK_LAUNCH("k_roipool_bwd");
     return DG_OK;
+}
+
+extern "C" int dg_roipool_bwd_f32(const float *grad_out, const int32_t *argmax, const int32_t *win, int64_t n,
+                                  int64_t B, int64_t C, int64_t H, int64_t W, int64_t P, int mode, float *grad_in,
+                                  void *ws, size_t ws_bytes, dg_stream_t s)
+{
+    return roipool_bwd(grad_out, argmax, false, win, n, B, C, H, W, P, mode, grad_in, ws, ws_bytes, s);
+}
+
+extern "C" int dg_roipool_bwd_a16_f32(const float *grad_out, const uint16_t *argmax16, const int32_t *win, int64_t n,
+                                      int64_t B, int64_t C, int64_t H, int64_t W, int64_t P, int mode, float *grad_in,
+                                      void *ws, size_t ws_bytes, dg_stream_t s)
+{
+    return roipool_bwd(grad_out, argmax16, true, win, n, B, C, H, W, P, mode, grad_in, ws, ws_bytes, s);
 }

@@ -199,7 +199,9 @@ def to_nhwc(img, out=None, nan_flag=None):
     return out, nan_flag
 
 
-def roipool_forward(img, win, mode="max", P=7, out=None, argmax=None, nhwc=None, nan_flag=None):
+def roipool_forward(img, win, mode="max", P=7, out=None, argmax=None, nhwc=None, nan_flag=None, argmax_dtype=torch.int32):
+    """argmax: int32 (default) or, with argmax_dtype=torch.int16 / an int16 tensor passed in, the uint16 bit pattern of the
+    same index (widen with `argmax_i32`): half the index bytes in the forward and the backward."""
     dev = img.device
     B, C_, H, W = img.shape
     n = win.shape[0]
@@ -209,11 +211,20 @@ def roipool_forward(img, win, mode="max", P=7, out=None, argmax=None, nhwc=None,
     if out is None:
         out = torch.empty((n, C_, P, P), dtype=torch.float32, device=dev)
     if m == _abi.POOL_MAX and argmax is None:
-        argmax = torch.empty((n, C_, P, P), dtype=torch.int32, device=dev)
+        argmax = torch.empty((n, C_, P, P), dtype=argmax_dtype, device=dev)
+    a16 = m == _abi.POOL_MAX and argmax.dtype == torch.int16
+    if m == _abi.POOL_MAX and argmax.dtype not in (torch.int32, torch.int16):
+        raise ValueError("roipool_forward: argmax must be int32 or int16 (uint16 bit pattern)")
+    fn = load().dg_roipool_fwd_a16_f32 if a16 else load().dg_roipool_fwd_f32
     with torch.cuda.device(dev):
-        check(load().dg_roipool_fwd_f32(ptr(nhwc), B, C_, H, W, ptr(win), n, P, m, ptr(nan_flag), ptr(out),
-                                        ptr(argmax) if m == _abi.POOL_MAX else None, stream_ptr(dev)))
+        check(fn(ptr(nhwc), B, C_, H, W, ptr(win), n, P, m, ptr(nan_flag), ptr(out),
+                 ptr(argmax) if m == _abi.POOL_MAX else None, stream_ptr(dev)))
     return out, (argmax if m == _abi.POOL_MAX else None)
+
+
+def argmax_i32(argmax):
+    """int32 view of an argmax tensor of either width (the 16-bit form holds the uint16 bit pattern)."""
+    return argmax if argmax.dtype == torch.int32 else argmax.to(torch.int32) & 0xFFFF
 
 
 def roipool_backward(grad_out, argmax, win, img_shape, mode="max", P=7, grad_in=None):
@@ -226,9 +237,9 @@ def roipool_backward(grad_out, argmax, win, img_shape, mode="max", P=7, grad_in=
     nbytes = load().dg_roipool_bwd_workspace_bytes(B, n)
     ws = workspace(dev, nbytes)
     m = _abi.POOL_MAX if mode == "max" else _abi.POOL_AVG
+    fn = load().dg_roipool_bwd_a16_f32 if (argmax is not None and argmax.dtype == torch.int16) else load().dg_roipool_bwd_f32
     with torch.cuda.device(dev):
-        check(load().dg_roipool_bwd_f32(ptr(g), ptr(argmax), ptr(win), n, B, C_, H, W, P, m, ptr(grad_in), ptr(ws), nbytes,
-                                        stream_ptr(dev)))
+        check(fn(ptr(g), ptr(argmax), ptr(win), n, B, C_, H, W, P, m, ptr(grad_in), ptr(ws), nbytes, stream_ptr(dev)))
     return grad_in
 
 
