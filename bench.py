@@ -26,7 +26,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-ROI_BYTES = 200704                # out + argmax bytes per RoI (512 ch x 49 x (4+4))
+ROI_BYTES = 200704                # out + argmax bytes per RoI (512 ch x 49 x (4+4)), int32 argmax as BASELINE configs[2] sizes it
+ROI_BYTES_A16 = 150528            # the uint16-argmax layout slowroipool's autograd path uses (512 ch x 49 x (4+2)): side measurement
 MAP_BYTES = 3891200               # one 512x38x50 fp32 map
 
 
@@ -299,6 +300,21 @@ def main():
                 "bytes_per_launch": fwd_bytes, "avg_launch_ms": t_fwd,
                 "bwd_frac": (w.n * ROI_BYTES + w.B * MAP_BYTES) / (phases["roipool_bwd_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS}
     gout_alias = w.gout_alias
+    # the same step with the argmax kept as uint16 (what slowroipool's autograd path does; H*W <= 65535): every rank runs it
+    a16 = None
+    if not a.no_extras:
+        try:
+            w.arg = torch.empty(tuple(w.out.shape), dtype=torch.int16, device=d.dev)
+            sec16 = d.timed(w.step, a.steps, 1)
+            f16, b16 = ev_time(w.fwd, 3, 1), ev_time(w.bwd, 3, 1)
+            a16 = {"value": total_rois * a.steps / sec16, "unit": "RoIs/s", "ms_per_step": sec16 / a.steps * 1e3,
+                   "roipool_fwd_ms": f16, "roipool_bwd_ms": b16, "bytes_per_roi": ROI_BYTES_A16,
+                   "fwd_hbm_frac": (w.n * ROI_BYTES_A16 + w.B * MAP_BYTES + w.n * 20) / (f16 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                   "bwd_hbm_frac": (w.n * ROI_BYTES_A16 + w.B * MAP_BYTES) / (b16 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                   "note": "same step, argmax stored as uint16 instead of int32: the primary line keeps the int32 layout "
+                           "BASELINE configs[2] sizes (51.4 GB of argmax); fractions here use this layout's own bytes"}
+        except torch.OutOfMemoryError as e:
+            a16 = {"error": str(e)}
     del w
     torch.cuda.empty_cache()
     # what a plain device-to-device copy reaches on this box (read + write bytes), as SURVEY 8(d) asks: the second yardstick
@@ -311,7 +327,7 @@ def main():
     roofline["d2d_copy_GBps"] = copy_gbps
     roofline["frac_of_d2d_copy"] = achieved / copy_gbps
 
-    extra = {"phases_ms_rank0": phases, "grad_out_aliases_out": gout_alias}
+    extra = {"phases_ms_rank0": phases, "grad_out_aliases_out": gout_alias, "config3_uint16_argmax": a16}
     def side(name, fn):
         # a side configuration that fails is reported as such; it must not cost the primary line
         try:

@@ -1,5 +1,5 @@
 """Profiling driver: runs one hot-path phase a few times (used under rocprofv3).
-usage: python3 tools/prof_roi.py {fwd|bwd|kmeans|nms64k|pairwise} [images]"""
+usage: python3 tools/prof_roi.py {fwd|bwd|kmeans|nms64k|pairwise} [images] [a32]   (RoI pooling: uint16 argmax unless a32)"""
 import os
 import sys
 
@@ -19,7 +19,8 @@ if what in ("fwd", "bwd"):
     idx = torch.arange(images, device=dev).repeat_interleave(2000)
     win, st = ops.roi_windows(rois, idx, images, 38, 50, dev)
     nhwc, nanf = ops.to_nhwc(img)
-    out, arg = ops.roipool_forward(img, win, "max", nhwc=nhwc, nan_flag=nanf)
+    adt = torch.int32 if (len(sys.argv) > 3 and sys.argv[3] == "a32") else torch.int16
+    out, arg = ops.roipool_forward(img, win, "max", nhwc=nhwc, nan_flag=nanf, argmax_dtype=adt)
     for _ in range(3):
         if what == "fwd":
             ops.roipool_forward(img, win, "max", out=out, argmax=arg, nhwc=nhwc, nan_flag=nanf)

@@ -774,6 +774,31 @@ __global__ __launch_bounds__(NT) void k_roipool_bwd(const float *__restrict__ gr
         const int per4 = per >> 2;                   // float4 groups per RoI
         const int64_t work = (int64_t)(r1 - r0) * per4;
         int64_t t = tid;
+        {
+            constexpr int U = 4;                            // groups of 4 elements in flight per thread (8: no further gain)
+            for (; t + (U - 1) * NT < work; t += U * NT) {
+                int64_t o[U];
+                int e[U];
+                float4 g[U];
+                int4 ix[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int64_t tu = t + u * NT;
+                    const int r = (int)(tu / per4), q = (int)(tu - (int64_t)r * per4);
+                    o[u] = ((int64_t)list[r0 + r] * C + c0) * RBINS + 4 * q;
+                    e[u] = 4 * q;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u) { g[u] = *reinterpret_cast<const float4 *>(grad_out + o[u]); ix[u] = idx4(o[u]); }
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    lds_fadd(&plane[((e[u] + 0) / RBINS) * HW + ix[u].x], g[u].x);
+                    lds_fadd(&plane[((e[u] + 1) / RBINS) * HW + ix[u].y], g[u].y);
+                    lds_fadd(&plane[((e[u] + 2) / RBINS) * HW + ix[u].z], g[u].z);
+                    lds_fadd(&plane[((e[u] + 3) / RBINS) * HW + ix[u].w], g[u].w);
+                }
+            }
+        }
         for (; t + NT < work; t += 2 * NT) {           // two independent 16-byte pairs in flight
             const int64_t t2 = t + NT;
             const int ra = (int)(t / per4), qa = (int)(t - (int64_t)ra * per4);

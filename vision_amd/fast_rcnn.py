@@ -17,7 +17,7 @@ from . import ops
 class _RoIPoolFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, img, win, mode):
-        out, argmax = ops.roipool_forward(img, win, mode)
+        out, argmax = ops.roipool_forward(img, win, mode, argmax_dtype=torch.int16)   # uint16 indices: half the bytes
         ctx.mode, ctx.img_shape = mode, tuple(img.shape)
         ctx.save_for_backward(win, argmax if argmax is not None else win)
         ctx.argmax = argmax
