@@ -68,8 +68,22 @@ def test_evaluate_and_ap(golden, oracle):
     for c in range(5):
         assert np.array_equal(np.array(det[c], np.float64).reshape(-1, 6), g[f"detects_{c}"]), c
         assert np.array_equal(np.array(tgt[c], np.float64).reshape(-1, 6), g[f"targets_{c}"]), c
-    assert np.allclose(oracle.average_precision(det, tgt, 0.05), g["aps_iou005"], rtol=0, atol=1e-12)
-    assert np.allclose(oracle.average_precision(det, tgt, 0.5), g["aps_iou05"], rtol=0, atol=1e-12)
+    assert np.array_equal(np.array(oracle.average_precision(det, tgt, 0.05)), g["aps_iou005"])      # float64, bit for bit
+    assert np.array_equal(np.array(oracle.average_precision(det, tgt, 0.5)), g["aps_iou05"])
+
+
+def test_ap_known_answers(oracle):
+    """hand-checkable cases of yolo.py:306-367: perfect detections, a duplicate counted as FP, a class without targets."""
+    box = [0.1, 0.1, 0.5, 0.5]
+    tgt = {0: [[0, 1] + box, [1, 1] + box], 1: []}
+    det = {0: [[0, 0.9] + box, [1, 0.8] + box], 1: []}
+    assert oracle.average_precision(det, tgt, 0.5) == [1.0, 0.0, 0.0]                 # the empty class appends 0.0 twice
+    det = {0: [[0, 0.9] + box, [0, 0.8] + box, [1, 0.7] + box], 1: []}                # second hit on image 0 is a FP
+    ap0 = oracle.average_precision(det, tgt, 0.5)[0]
+    assert ap0 == 0.5 * 1.0 + 0.5 * (2.0 / 3.0)
+    det = {0: [], 1: [[0, 0.9] + box]}                                                # detections but no targets: 0/0 recall
+    out = oracle.average_precision(det, tgt, 0.5)
+    assert out[0] == 0.0 and out[1] == 0.0 and np.isnan(out[2])
 
 
 def test_roipool(golden, oracle):
