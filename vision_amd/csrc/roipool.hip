@@ -741,6 +741,29 @@ __device__ __forceinline__ void lds_fadd4(float *p, int stride, const float (&g)
     }
 }
 
+// four channels of one pixel in a [pixel][4] plane: one 16-byte read and two 64-bit compare-and-swap adds
+__device__ __forceinline__ void lds_fadd_px4(float *p, const float (&g)[4])
+{
+    unsigned long long *q = reinterpret_cast<unsigned long long *>(p);
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    const u64x2 cur = *reinterpret_cast<volatile u64x2 *>(p);
+    unsigned long long old[2] = {cur.x, cur.y};
+    bool done[2] = {false, false};
+    while (true) {
+        unsigned long long got[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float lo = __int_as_float((int)(unsigned)old[h]) + g[2 * h], hi = __int_as_float((int)(unsigned)(old[h] >> 32)) + g[2 * h + 1];
+            const unsigned long long want = ((unsigned long long)(unsigned)__float_as_int(hi) << 32) | (unsigned)__float_as_int(lo);
+            got[h] = done[h] ? old[h] : atomicCAS(q + h, old[h], want);
+        }
+        bool all = true;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) { done[h] = done[h] || (got[h] == old[h]); old[h] = got[h]; all = all && done[h]; }
+        if (all) break;
+    }
+}
+
 // grid: x = channel block (CB channels), y = image.  Dynamic LDS: CB*H*W floats.
 // VEC: CB*49 % 4 == 0 and 16-byte aligned tensors -> each thread moves 4 consecutive elements of one RoI
 // (16-byte loads of grad_out and argmax), two such groups in flight per thread.
@@ -837,7 +860,7 @@ __global__ __launch_bounds__(NT) void k_roipool_bwd(const float *__restrict__ gr
         // each pixel sums the shares of the bins that contain it (1..2 per axis, more for crops under 7) and is added
         // ONCE to the LDS plane.  The scatter form (every bin looping over its pixels) costs several times as many LDS
         // read-modify-writes.  The window of the next RoI is fetched while the current one is processed.
-        __shared__ float share[NT / 64][16 * 64];                 // [wave][channel (<= 16)][bin]
+        __shared__ __attribute__((aligned(16))) float share[NT / 64][16 * 64];   // [wave][channel (<= 16)][bin]; cb == 4: [wave][bin][4]
         __shared__ unsigned char binlo[NT / 64][2][64], binhi[NT / 64][2][64];   // [wave][axis][coordinate]
         const int lane = tid & 63, wave = tid >> 6;
         // software pipeline over the wave's RoIs: the RoI index is fetched two ahead, window and bin gradients one ahead
@@ -868,15 +891,24 @@ __global__ __launch_bounds__(NT) void k_roipool_bwd(const float *__restrict__ gr
             if (rr + NT / 64 < nr) fetch_roi(roi1);
             roi2 = (rr + 2 * (NT / 64) < nr) ? list[r0 + rr + 2 * (NT / 64)] : 0;
             const bool small = Lh <= 64 && Lw <= 64;
+            // a / L for 0 <= a < 2^10 and L <= 64 without the ~35-instruction integer division: (a + 0.5) / L is at
+            // least 1/128 away from every integer, far more than the error of rcp and one multiply
+            const float rLh = __builtin_amdgcn_rcpf((float)Lh), rLw = __builtin_amdgcn_rcpf((float)Lw);
+            auto fdiv = [](int a, float rcp) { return (int)(((float)a + 0.5f) * rcp); };
             if (small) {
                 // bins whose range [floor(i*L/7), ceil((i+1)*L/7)) contains coordinate `lane`
-                if (lane < Lh) { binlo[wave][0][lane] = (unsigned char)((lane * RP) / Lh); binhi[wave][0][lane] = (unsigned char)(((lane + 1) * RP + Lh - 1) / Lh - 1); }
-                if (lane < Lw) { binlo[wave][1][lane] = (unsigned char)((lane * RP) / Lw); binhi[wave][1][lane] = (unsigned char)(((lane + 1) * RP + Lw - 1) / Lw - 1); }
+                if (lane < Lh) { binlo[wave][0][lane] = (unsigned char)fdiv(lane * RP, rLh); binhi[wave][0][lane] = (unsigned char)(fdiv((lane + 1) * RP + Lh - 1, rLh) - 1); }
+                if (lane < Lw) { binlo[wave][1][lane] = (unsigned char)fdiv(lane * RP, rLw); binhi[wave][1][lane] = (unsigned char)(fdiv((lane + 1) * RP + Lw - 1, rLw) - 1); }
             }
             if (lane < RBINS) {
                 const int ph = lane / RP, pw = lane - ph * RP;
                 const float kh = (float)(((ph + 1) * Lh + RP - 1) / RP - (ph * Lh) / RP), kw = (float)(((pw + 1) * Lw + RP - 1) / RP - (pw * Lw) / RP);
-                if (cb <= 4) {
+                if (cb == 4) {                       // the usual slice: the four channels of a bin side by side
+                    // g * (1 / (kh*kw)): one division per bin instead of eight; within 2 ulp of ATen's g / kh / kw, far
+                    // inside the accumulation-order tolerance of this kernel
+                    const float inv = 1.0f / (kh * kw);
+                    *reinterpret_cast<float4 *>(&share[wave][lane * 4]) = make_float4(gc[0] * inv, gc[1] * inv, gc[2] * inv, gc[3] * inv);
+                } else if (cb < 4) {
 #pragma unroll
                     for (int ch = 0; ch < 4; ++ch) share[wave][ch * 64 + lane] = gc[ch] / kh / kw;
                 } else {
@@ -890,8 +922,8 @@ __global__ __launch_bounds__(NT) void k_roipool_bwd(const float *__restrict__ gr
             float *pl = plane + y1 * W + x1;
             // lanes cover whole crop rows: 64 / Lw rows per pass (a 9-wide crop keeps 63 lanes busy; fixed 8x8 tiles kept
             // 81 of 256).  Crops wider than 64 cells walk 64-cell row segments.
-            const int rpp = Lw <= 64 ? 64 / Lw : 1;                      // rows per pass
-            const int lyy = Lw <= 64 ? lane / Lw : 0, lxx = Lw <= 64 ? lane - lyy * Lw : lane;
+            const int rpp = Lw <= 64 ? fdiv(64, rLw) : 1;                // rows per pass
+            const int lyy = Lw <= 64 ? fdiv(lane, rLw) : 0, lxx = Lw <= 64 ? lane - lyy * Lw : lane;
             const bool lane_on = Lw <= 64 ? lyy < rpp : true;
             for (int ty = 0; ty < Lh; ty += rpp) {
                 for (int tx = 0; tx < Lw; tx += 64) {
@@ -900,15 +932,14 @@ __global__ __launch_bounds__(NT) void k_roipool_bwd(const float *__restrict__ gr
                         int ph0, ph1, pw0, pw1;
                         if (small) { ph0 = binlo[wave][0][ry]; ph1 = binhi[wave][0][ry]; pw0 = binlo[wave][1][rx]; pw1 = binhi[wave][1][rx]; }
                         else { ph0 = (ry * RP) / Lh; ph1 = ((ry + 1) * RP + Lh - 1) / Lh - 1; pw0 = (rx * RP) / Lw; pw1 = ((rx + 1) * RP + Lw - 1) / Lw - 1; }
-                        if (cb == 4) {                       // the usual slice: four independent chains in flight
+                        if (cb == 4) {                       // plane is [pixel][4 channels]: one 16-byte read per share, two 64-bit CAS
                             float sum[4] = {0.f, 0.f, 0.f, 0.f};
                             for (int ph = ph0; ph <= ph1; ++ph)
                                 for (int pw = pw0; pw <= pw1; ++pw) {
-                                    const float *sp = &share[wave][ph * RP + pw];
-#pragma unroll
-                                    for (int ch = 0; ch < 4; ++ch) sum[ch] += sp[ch * 64];
+                                    const float4 sp = *reinterpret_cast<const float4 *>(&share[wave][(ph * RP + pw) * 4]);
+                                    sum[0] += sp.x; sum[1] += sp.y; sum[2] += sp.z; sum[3] += sp.w;
                                 }
-                            lds_fadd4(&pl[ry * W + rx], HW, sum);
+                            lds_fadd_px4(&plane[((y1 + ry) * W + (x1 + rx)) * 4], sum);
                         } else {
                             for (int ch = 0; ch < cb; ++ch) {
                                 float sum = 0.f;
@@ -933,7 +964,13 @@ __global__ __launch_bounds__(NT) void k_roipool_bwd(const float *__restrict__ gr
     }
     __syncthreads();
     float *gi = grad_in + ((int64_t)b * C + c0) * HW;
-    if (gridDim.z == 1) {
+    if (MODE == DG_POOL_AVG && cb == 4) {              // [pixel][4] in LDS -> four NCHW planes
+        for (int i = tid; i < 4 * HW; i += NT) {
+            const int ch = i / HW, px = i - ch * HW;
+            if (gridDim.z == 1) gi[i] = plane[px * 4 + ch];
+            else atomicAdd(&gi[i], plane[px * 4 + ch]);
+        }
+    } else if (gridDim.z == 1) {
         for (int i = tid; i < cb * HW; i += NT) gi[i] = plane[i];
     } else {
         for (int i = tid; i < cb * HW; i += NT) atomicAdd(&gi[i], plane[i]);
