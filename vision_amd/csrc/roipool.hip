@@ -891,6 +891,7 @@ __global__ __launch_bounds__(NT) void k_roipool_bwd(const float *__restrict__ gr
             if (rr + NT / 64 < nr) fetch_roi(roi1);
             roi2 = (rr + 2 * (NT / 64) < nr) ? list[r0 + rr + 2 * (NT / 64)] : 0;
             const bool small = Lh <= 64 && Lw <= 64;
+            const bool two_max = Lh >= RP && Lw >= RP;                   // uniform
             // a / L for 0 <= a < 2^10 and L <= 64 without the ~35-instruction integer division: (a + 0.5) / L is at
             // least 1/128 away from every integer, far more than the error of rcp and one multiply
             const float rLh = __builtin_amdgcn_rcpf((float)Lh), rLw = __builtin_amdgcn_rcpf((float)Lw);
@@ -934,11 +935,25 @@ __global__ __launch_bounds__(NT) void k_roipool_bwd(const float *__restrict__ gr
                         else { ph0 = (ry * RP) / Lh; ph1 = ((ry + 1) * RP + Lh - 1) / Lh - 1; pw0 = (rx * RP) / Lw; pw1 = ((rx + 1) * RP + Lw - 1) / Lw - 1; }
                         if (cb == 4) {                       // plane is [pixel][4 channels]: one 16-byte read per share, two 64-bit CAS
                             float sum[4] = {0.f, 0.f, 0.f, 0.f};
-                            for (int ph = ph0; ph <= ph1; ++ph)
-                                for (int pw = pw0; pw <= pw1; ++pw) {
-                                    const float4 sp = *reinterpret_cast<const float4 *>(&share[wave][(ph * RP + pw) * 4]);
-                                    sum[0] += sp.x; sum[1] += sp.y; sum[2] += sp.z; sum[3] += sp.w;
-                                }
+                            if (two_max) {
+                                // crops of at least 7x7: a pixel lies in one or two bins per axis -- four fixed reads, the
+                                // repeats (ph1 == ph0 / pw1 == pw0) masked out by selects (not 0/1 factors: 0 * inf), no divergent loops
+                                const bool mh = ph1 > ph0, mw = pw1 > pw0, mhw = mh && mw;
+                                const float4 a = *reinterpret_cast<const float4 *>(&share[wave][(ph0 * RP + pw0) * 4]);
+                                const float4 b2 = *reinterpret_cast<const float4 *>(&share[wave][(ph0 * RP + pw1) * 4]);
+                                const float4 c2 = *reinterpret_cast<const float4 *>(&share[wave][(ph1 * RP + pw0) * 4]);
+                                const float4 d2 = *reinterpret_cast<const float4 *>(&share[wave][(ph1 * RP + pw1) * 4]);
+                                sum[0] = ((a.x + (mw ? b2.x : 0.f)) + (mh ? c2.x : 0.f)) + (mhw ? d2.x : 0.f);
+                                sum[1] = ((a.y + (mw ? b2.y : 0.f)) + (mh ? c2.y : 0.f)) + (mhw ? d2.y : 0.f);
+                                sum[2] = ((a.z + (mw ? b2.z : 0.f)) + (mh ? c2.z : 0.f)) + (mhw ? d2.z : 0.f);
+                                sum[3] = ((a.w + (mw ? b2.w : 0.f)) + (mh ? c2.w : 0.f)) + (mhw ? d2.w : 0.f);
+                            } else {
+                                for (int ph = ph0; ph <= ph1; ++ph)
+                                    for (int pw = pw0; pw <= pw1; ++pw) {
+                                        const float4 sp = *reinterpret_cast<const float4 *>(&share[wave][(ph * RP + pw) * 4]);
+                                        sum[0] += sp.x; sum[1] += sp.y; sum[2] += sp.z; sum[3] += sp.w;
+                                    }
+                            }
                             lds_fadd_px4(&plane[((y1 + ry) * W + (x1 + rx)) * 4], sum);
                         } else {
                             for (int ch = 0; ch < cb; ++ch) {
