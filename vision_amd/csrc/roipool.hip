@@ -854,14 +854,14 @@ __global__ __launch_bounds__(NT) void k_roipool_bwd(const float *__restrict__ gr
             lds_fadd(&plane[((ea + 3) / RBINS) * HW + ia.w], ga.w);
         }
     } else if (MODE == DG_POOL_AVG) {
-        // avg mode, one wave per RoI (all channels of the slice).  The bin gradients become per-pixel shares
-        // g/rows/cols in a per-wave LDS scratch, the bins covering each crop row / column come from a small table
-        // (one integer division per row and column, not per pixel), and the lanes then walk the crop in 8x8 tiles:
-        // each pixel sums the shares of the bins that contain it (1..2 per axis, more for crops under 7) and is added
-        // ONCE to the LDS plane.  The scatter form (every bin looping over its pixels) costs several times as many LDS
-        // read-modify-writes.  The window of the next RoI is fetched while the current one is processed.
-        __shared__ __attribute__((aligned(16))) float share[NT / 64][16 * 64];   // [wave][channel (<= 16)][bin]; cb == 4: [wave][bin][4]
-        __shared__ unsigned char binlo[NT / 64][2][64], binhi[NT / 64][2][64];   // [wave][axis][coordinate]
+        // avg mode, one wave per RoI (all channels of the slice, at most 4).  The bin gradients become per-pixel shares
+        // g/(rows*cols) in a per-wave LDS scratch; the lanes then cover whole crop rows (64 / width rows per pass), each
+        // pixel sums the shares of the bins that contain it (1..2 per axis, more for crops under 7; the bin ranges come
+        // from reciprocal multiplies, not integer divisions) and is added ONCE to the LDS plane, which is laid out
+        // [pixel][4 channels] so that one 16-byte read and two 64-bit compare-and-swaps serve the four channels.  The
+        // scatter form (every bin looping over its pixels) costs several times as many LDS read-modify-writes.  The
+        // window and bin gradients of the next RoI are fetched while the current one is processed.
+        __shared__ __attribute__((aligned(16))) float share[NT / 64][4 * 64];    // cb == 4: [wave][bin][4]; cb < 4: [wave][channel][bin]; the host keeps CB <= 4 in avg mode
         const int lane = tid & 63, wave = tid >> 6;
         // software pipeline over the wave's RoIs: the RoI index is fetched two ahead, window and bin gradients one ahead
         const int nr = r1 - r0;
@@ -881,7 +881,6 @@ __global__ __launch_bounds__(NT) void k_roipool_bwd(const float *__restrict__ gr
         };
         if (rr < nr) fetch_roi(roi1);
         for (; rr < nr; rr += NT / 64) {
-            const int roi = __builtin_amdgcn_readfirstlane(roi1);
             const int x1 = __builtin_amdgcn_readfirstlane(wn.x), y1 = __builtin_amdgcn_readfirstlane(wn.y);
             const int Lw = __builtin_amdgcn_readfirstlane(wn.z) - x1, Lh = __builtin_amdgcn_readfirstlane(wn.w) - y1;
             float gc[4];
@@ -896,11 +895,6 @@ __global__ __launch_bounds__(NT) void k_roipool_bwd(const float *__restrict__ gr
             // least 1/128 away from every integer, far more than the error of rcp and one multiply
             const float rLh = __builtin_amdgcn_rcpf((float)Lh), rLw = __builtin_amdgcn_rcpf((float)Lw);
             auto fdiv = [](int a, float rcp) { return (int)(((float)a + 0.5f) * rcp); };
-            if (small) {
-                // bins whose range [floor(i*L/7), ceil((i+1)*L/7)) contains coordinate `lane`
-                if (lane < Lh) { binlo[wave][0][lane] = (unsigned char)fdiv(lane * RP, rLh); binhi[wave][0][lane] = (unsigned char)(fdiv((lane + 1) * RP + Lh - 1, rLh) - 1); }
-                if (lane < Lw) { binlo[wave][1][lane] = (unsigned char)fdiv(lane * RP, rLw); binhi[wave][1][lane] = (unsigned char)(fdiv((lane + 1) * RP + Lw - 1, rLw) - 1); }
-            }
             if (lane < RBINS) {
                 const int ph = lane / RP, pw = lane - ph * RP;
                 const float kh = (float)(((ph + 1) * Lh + RP - 1) / RP - (ph * Lh) / RP), kw = (float)(((pw + 1) * Lw + RP - 1) / RP - (pw * Lw) / RP);
@@ -909,12 +903,9 @@ __global__ __launch_bounds__(NT) void k_roipool_bwd(const float *__restrict__ gr
                     // inside the accumulation-order tolerance of this kernel
                     const float inv = 1.0f / (kh * kw);
                     *reinterpret_cast<float4 *>(&share[wave][lane * 4]) = make_float4(gc[0] * inv, gc[1] * inv, gc[2] * inv, gc[3] * inv);
-                } else if (cb < 4) {
+                } else {
 #pragma unroll
                     for (int ch = 0; ch < 4; ++ch) share[wave][ch * 64 + lane] = gc[ch] / kh / kw;
-                } else {
-                    const float *g = grad_out + ((int64_t)roi * C + c0) * RBINS + lane;
-                    for (int ch = 0; ch < cb; ++ch) share[wave][ch * 64 + lane] = g[ch * RBINS] / kh / kw;
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -931,7 +922,8 @@ __global__ __launch_bounds__(NT) void k_roipool_bwd(const float *__restrict__ gr
                     const int ry = ty + lyy, rx = tx + lxx;
                     if (lane_on && ry < Lh && rx < Lw) {
                         int ph0, ph1, pw0, pw1;
-                        if (small) { ph0 = binlo[wave][0][ry]; ph1 = binhi[wave][0][ry]; pw0 = binlo[wave][1][rx]; pw1 = binhi[wave][1][rx]; }
+                        // bins whose range [floor(i*L/7), ceil((i+1)*L/7)) contains the coordinate
+                        if (small) { ph0 = fdiv(ry * RP, rLh); ph1 = fdiv((ry + 1) * RP + Lh - 1, rLh) - 1; pw0 = fdiv(rx * RP, rLw); pw1 = fdiv((rx + 1) * RP + Lw - 1, rLw) - 1; }
                         else { ph0 = (ry * RP) / Lh; ph1 = ((ry + 1) * RP + Lh - 1) / Lh - 1; pw0 = (rx * RP) / Lw; pw1 = ((rx + 1) * RP + Lw - 1) / Lw - 1; }
                         if (cb == 4) {                       // plane is [pixel][4 channels]: one 16-byte read per share, two 64-bit CAS
                             float sum[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1100,7 +1092,7 @@ static int roipool_bwd(const float *grad_out, const void *argmax, bool a16, cons
     // channels per workgroup: as many as fit ~32 KiB of LDS, but keep >= ~1024 workgroups when possible
     int CB = 1;
     while (CB < 4 && (int64_t)CB * 2 * HW * 4 <= 32 * 1024 && CB * 2 <= C) CB *= 2;      // 4 channels: 16-byte vector path
-    while (CB < 16 && (int64_t)CB * 2 * HW * 4 <= 32 * 1024 && B * dg_cdiv(C, CB * 2) >= 1024) CB *= 2;
+    while (mode == DG_POOL_MAX && CB < 16 && (int64_t)CB * 2 * HW * 4 <= 32 * 1024 && B * dg_cdiv(C, CB * 2) >= 1024) CB *= 2;
     int64_t S = 1;                                     // RoI-list splits when there are too few (image, slice) pairs
     while (S < 16 && B * dg_cdiv(C, CB) * S < 1024 && n / (B * S * 2) >= 64) S *= 2;
     dim3 grid((unsigned)dg_cdiv(C, CB), (unsigned)B, (unsigned)S);
