@@ -88,7 +88,8 @@ class Dist:
 # ------------------------------------------------------------------ config 3 (primary) / config 1
 class FrcnnBatch:
     def __init__(self, d, images_total, n_rois=2000, C=512, H=38, W=50, nms_thr=0.7):
-        from vision_amd import ops, shard, workloads as wl
+        from vision_amd import ops, shard
+        from tools import workloads as wl
         self.ops, self.d = ops, d
         first, last = shard.shard_range(images_total, d.rank, d.world)     # contiguous image range of this rank
         per = last - first
@@ -143,7 +144,7 @@ class FrcnnBatch:
 def cpu_baseline_frcnn(images=12, n_rois=2000):
     """CPU oracle (scalar C port of the reference algorithm), one core, same step on a bounded sample."""
     from oracle import oracle as orc
-    from vision_amd import workloads as wl
+    from tools import workloads as wl
     orc.build()
     img = wl.frcnn_feature_map(0, images)
     rois = np.concatenate([wl.frcnn_rois(i, n_rois) for i in range(images)])
@@ -186,7 +187,8 @@ class _solo:
 
 
 def extra_yolo(d):
-    from vision_amd import yolo_v1, workloads as wl
+    from vision_amd import yolo_v1
+    from tools import workloads as wl
     out, tgt = wl.yolo1_batch(0, 64)
     o, t = torch.from_numpy(out).to(d.dev), torch.from_numpy(tgt).to(d.dev)
     ms = ev_time(lambda: yolo_v1.decode_nms_batched(o, t, 0.2, 0.01, 0.3), 50, 5)
@@ -199,7 +201,8 @@ def extra_yolo(d):
 
 
 def extra_stress(d, n=65536):
-    from vision_amd import ops, workloads as wl, _abi
+    from vision_amd import ops, _abi
+    from tools import workloads as wl
     r = {}
     b, s = wl.stress_boxes(0, n, dense=False)
     bt, st = torch.from_numpy(b).to(d.dev), torch.from_numpy(s).to(d.dev)
@@ -231,7 +234,8 @@ def extra_stress(d, n=65536):
 
 
 def extra_kmeans(d, n_total=10_000_000, iters=30):
-    from vision_amd import cluster, shard as sh, workloads as wl
+    from vision_amd import cluster, shard as sh
+    from tools import workloads as wl
     wh_all = wl.anchor_wh(0, n_total)
     init = cluster.kmean.init_centers(wh_all, 5, 42)
     lo, hi = sh.shard_range(n_total, d.rank, d.world)

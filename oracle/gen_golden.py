@@ -33,7 +33,7 @@ import torch.nn as nn
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from vision_amd import workloads as wl  # noqa: E402
+from tools import workloads as wl  # noqa: E402
 
 REF = os.environ.get("REFERENCE_ROOT", "/root/reference")
 OUT = os.path.join(ROOT, "tests", "golden")

@@ -13,7 +13,8 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from vision_amd import cluster, shard, workloads as wl
+from vision_amd import cluster, shard
+from tools import workloads as wl
 
 
 def test_shard_range_covers_everything():

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from vision_amd import workloads as wl
+from tools import workloads as wl
 
 pytestmark = pytest.mark.gpu
 

@@ -8,7 +8,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from vision_amd import workloads as wl  # noqa: E402
+from tools import workloads as wl  # noqa: E402
 
 
 @pytest.fixture(scope="module")

@@ -136,7 +136,7 @@ def test_do_ss_quota(golden, oracle):
 
 def test_kmeans_spec_selfconsistency(oracle):
     """1-IoU k-means is NOT in the reference (parity unpinned): only the spec's own invariants."""
-    from vision_amd import workloads as wl
+    from tools import workloads as wl
     wh = wl.anchor_wh(0, 20000)
     cent, labels, n_iter, inertia = oracle.kmeans_fit(wh, 5, 42)
     assert cent.shape == (5, 2) and labels.shape == (20000,) and 1 <= n_iter <= 300
@@ -175,7 +175,7 @@ def test_yolo1_loss_oracle_vs_reference(golden, oracle):
 
 def test_yolo1_encode_restatement_vs_reference(golden):
     """workloads.yolo1_encode (the NumPy restatement used for synthetic targets) against the reference's encode."""
-    from vision_amd import workloads as wl
+    from tools import workloads as wl
     g = golden("yolo1_encode")
     for k in range(len(g["bb"])):
         C = 5 if k < 30 else 20

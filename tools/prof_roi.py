@@ -8,7 +8,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from vision_amd import ops, workloads as wl  # noqa: E402
+from vision_amd import ops
+from tools import workloads as wl  # noqa: E402
 
 what = sys.argv[1] if len(sys.argv) > 1 else "fwd"
 images = int(sys.argv[2]) if len(sys.argv) > 2 else 8

@@ -3,7 +3,8 @@ Timing-dependent faults (an LDS-DMA / ds_read race was found this way) need many
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
-from vision_amd import ops, workloads as wl
+from vision_amd import ops
+from tools import workloads as wl
 from oracle import oracle
 bad = 0
 t0 = time.time()

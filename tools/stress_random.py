@@ -3,7 +3,8 @@ channel counts, NaN maps, ragged batches.  One-off (minutes of GPU time), comple
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
-from vision_amd import ops, workloads as wl
+from vision_amd import ops
+from tools import workloads as wl
 from oracle import oracle
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 40

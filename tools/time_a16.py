@@ -2,7 +2,8 @@
 import sys
 import numpy as np, torch
 sys.path.insert(0, ".")
-from vision_amd import ops, workloads as wl
+from vision_amd import ops
+from tools import workloads as wl
 images = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 dev = torch.device("cuda", 0)
 img = torch.randn((images, 512, 38, 50), device=dev)

@@ -2,7 +2,8 @@
 import sys
 import torch
 sys.path.insert(0, ".")
-from vision_amd import ops, workloads as wl
+from vision_amd import ops
+from tools import workloads as wl
 for k in (5, 9):
     wh = torch.from_numpy(wl.anchor_wh(0, 10_000_000)).cuda(); c = wh[:k].clone()
     l = torch.zeros(wh.shape[0], dtype=torch.uint8, device="cuda"); a = torch.zeros(3 * k + 2, dtype=torch.int64, device="cuda")

@@ -3,7 +3,8 @@ on one GPU with the all-reduce stubbed out, against the device-side loop of the 
 import sys, time
 import torch
 sys.path.insert(0, ".")
-from vision_amd import cluster, workloads as wl
+from vision_amd import cluster
+from tools import workloads as wl
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_250_000         # default: one rank's shard at 8 GPUs
 wh = torch.from_numpy(wl.anchor_wh(0, n)).cuda()
 init = cluster.kmean.init_centers(wh.cpu().numpy(), 5, 42)

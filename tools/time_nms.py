@@ -2,7 +2,8 @@
 import sys, time
 import numpy as np, torch
 sys.path.insert(0, ".")
-from vision_amd import ops, workloads as wl, _abi
+from vision_amd import ops, _abi
+from tools import workloads as wl
 from vision_amd._abi import load, check, ptr, stream_ptr
 
 def phases(b, s, thr, reps=5):
