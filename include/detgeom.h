@@ -63,7 +63,17 @@ size_t dg_nms_workspace_bytes(int64_t batch, int64_t nmax);
 int dg_nms_batched_f32(const float *boxes, const float *scores, const int32_t *counts, int64_t batch, int64_t nmax,
                        float threshold, int quirk_drop_last, int64_t *keep, int32_t *keep_count,
                        void *ws, size_t ws_bytes, dg_stream_t s);
-/* phases of the above, exposed for measurement (bench.py) and tests; same workspace */
+/* The same NMS for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  The workspace is a file-scope device array inside the library
+ * (DG_NMS_NOALLOC_SCRATCH_BYTES per GPU, held until the process ends); the call allocates nothing.  Sizes whose
+ * dg_nms_workspace_bytes(batch, nmax) exceeds that (12 images x 2000 boxes or one image of 9,800 boxes still fit) are refused
+ * with DG_ENOMEM and a message that names both figures.
+ * All calls on one GPU share that GPU's array: calls that overlap on one GPU (different streams / threads) race. */
+#define DG_NMS_NOALLOC_SCRATCH_BYTES (16u << 20)
+size_t dg_nms_noalloc_max_bytes(void);
+int dg_nms_batched_noalloc_f32(const float *boxes, const float *scores, const int32_t *counts, int64_t batch, int64_t nmax,
+                               float threshold, int quirk_drop_last, int64_t *keep, int32_t *keep_count, dg_stream_t s);
+/* phases of dg_nms_batched_f32, exposed for measurement (bench.py) and tests; same workspace */
 int dg_nms_phase_sort(const float *boxes, const float *scores, const int32_t *counts, int64_t batch, int64_t nmax,
                       void *ws, size_t ws_bytes, dg_stream_t s);
 int dg_nms_phase_mask(const int32_t *counts, int64_t batch, int64_t nmax, float threshold,

@@ -28,6 +28,8 @@ SIGNATURES = {
     "dg_iou_rois_vs_gt_f64": (C.c_int, [_vp, _vp, _i64, _vp, _vp, _vp]),
     "dg_nms_workspace_bytes": (_sz, [_i64, _i64]),
     "dg_nms_batched_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _f32, C.c_int, _vp, _vp, _vp, _sz, _vp]),
+    "dg_nms_noalloc_max_bytes": (_sz, []),
+    "dg_nms_batched_noalloc_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _f32, C.c_int, _vp, _vp, _vp]),
     "dg_nms_phase_sort": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _sz, _vp]),
     "dg_nms_phase_mask": (C.c_int, [_vp, _i64, _i64, _f32, _vp, _sz, _vp]),
     "dg_nms_phase_reduce": (C.c_int, [_vp, _i64, _i64, C.c_int, _vp, _vp, _vp, _sz, _vp]),

@@ -971,3 +971,58 @@ extern "C" int dg_nms_batched_f32(const float *boxes, const float *scores, const
     if (rc) return rc;
     return dg_nms_phase_reduce(counts, batch, nmax, quirk_drop_last, keep, keep_count, ws, ws_bytes, s);
 }
+
+// ---------------------------------------------------------------- allocation-free variant
+// dg_nms_batched_f32 with its workspace inside the library: a file-scope device array, one copy per GPU, held until the
+// process ends.  For callers that cannot allocate (HIP graph capture, tight serving loops).  `scratch` is only a host-side
+// stand-in for the array: its device address is looked up once per device with hipGetSymbolAddress and that pointer is
+// what the kernels get.  Every call on a GPU shares that GPU's array (calls overlapping on one GPU race); no phase
+// relies on its previous contents (the mask / summary / run words a reduce reads are all written by the same call).
+static __device__ __align__(256) unsigned char scratch[DG_NMS_NOALLOC_SCRATCH_BYTES];
+
+#include <mutex>
+#define NMS_MAX_DEVICES 64
+static void *g_scratch_ptr[NMS_MAX_DEVICES];      // device address of `scratch` on each device (0 = not looked up yet)
+static std::mutex g_scratch_mu;
+
+static int nms_scratch_ptr(void **out)
+{
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= NMS_MAX_DEVICES) {
+        dg_set_error("nms_noalloc: no current device (or device index >= %d)", NMS_MAX_DEVICES);
+        return DG_EHIP;
+    }
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[dev]) {
+        void *p = nullptr;
+        hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess || !p) {
+            dg_set_error("nms_noalloc: hipGetSymbolAddress(scratch) failed on device %d: %s", dev, hipGetErrorString(e));
+            return DG_EHIP;
+        }
+        g_scratch_ptr[dev] = p;
+    }
+    *out = g_scratch_ptr[dev];
+    return DG_OK;
+}
+
+extern "C" size_t dg_nms_noalloc_max_bytes(void) { return (size_t)DG_NMS_NOALLOC_SCRATCH_BYTES; }
+
+extern "C" int dg_nms_batched_noalloc_f32(const float *boxes, const float *scores, const int32_t *counts, int64_t batch,
+                                          int64_t nmax, float threshold, int quirk_drop_last, int64_t *keep,
+                                          int32_t *keep_count, dg_stream_t s)
+{
+    DG_REQUIRE(batch >= 0 && nmax >= 0, "nms_noalloc: negative size");
+    const size_t need = (batch > 0 && nmax > 0) ? dg_nms_workspace_bytes(batch, nmax) : 0;
+    if (need > (size_t)DG_NMS_NOALLOC_SCRATCH_BYTES) {
+        dg_set_error("nms_noalloc: batch %lld x nmax %lld needs %zu bytes of scratch, the built-in buffer holds %zu "
+                     "(use dg_nms_batched_f32 with a caller workspace)",
+                     (long long)batch, (long long)nmax, need, (size_t)DG_NMS_NOALLOC_SCRATCH_BYTES);
+        return DG_ENOMEM;
+    }
+    void *ws = nullptr;
+    int rc = nms_scratch_ptr(&ws);
+    if (rc) return rc;
+    return dg_nms_batched_f32(boxes, scores, counts, batch, nmax, threshold, quirk_drop_last, keep, keep_count, ws,
+                              (size_t)DG_NMS_NOALLOC_SCRATCH_BYTES, s);
+}
