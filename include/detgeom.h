@@ -148,6 +148,17 @@ int dg_roipool_bwd_a16_f32(const float *grad_out, const uint16_t *argmax16, cons
 size_t dg_kmeans_workspace_bytes(int64_t n, int64_t k);
 int dg_kmeans_iou_step(const float *wh, int64_t n, const float *cent, int64_t k, uint8_t *labels, int64_t *acc,
                        void *ws, size_t ws_bytes, dg_stream_t s);
+/* One iteration of the SHARDED Lloyd loop as ONE launch: the centroid update is the prologue of the next step, so an
+ * iteration costs one launch + one all-reduce of acc.  apply_prev != 0: acc holds the ALL-REDUCED sums of the previous
+ * iteration; every workgroup first moves the centroids by them (as dg_kmeans_update would), the new centroids are
+ * written back to cent and history[slot] (may be NULL) receives the previous iteration's changed count; then the step
+ * runs and acc is OVERWRITTEN with this shard's sums.  apply_prev == 0: a plain step (first iteration of a sequence).
+ * want_inertia == 0 leaves acc[3k+1] = 0.  After the last iteration call dg_kmeans_update on the all-reduced acc.
+ * A call with apply_prev != 0 must follow a dg_kmeans_iou_iter call on the same workspace, stream-ordered, with no
+ * other user of that workspace in between. */
+int dg_kmeans_iou_iter(const float *wh, int64_t n, float *cent, int64_t k, uint8_t *labels, int64_t *acc,
+                       int apply_prev, int want_inertia, int64_t *history, int64_t slot, void *ws, size_t ws_bytes,
+                       dg_stream_t s);
 /* centroid = sum/count (int64 fixed point 2^32 -> fp32); empty cluster keeps its centroid.
  * history (may be NULL): history[slot] = acc[3k] (changed count of this iteration). */
 int dg_kmeans_update(const int64_t *acc, int64_t k, float *cent, int64_t *history, int64_t slot, dg_stream_t s);

@@ -52,6 +52,13 @@ class OracleBackend:
         self.cent = self.orc.kmeans_update(a, self.cent)
         self.history[slot] = a[3 * self.k]
 
+    def iterate(self, apply_prev, inertia, slot):
+        if apply_prev:
+            self.update(slot)
+        self.step()
+        if not inertia:
+            self.acc[3 * self.k + 1] = 0
+
     def run_local(self, slot0, iters):
         for t in range(iters):
             self.step(); self.update(slot0 + t)

@@ -581,6 +581,71 @@ def test_kmeans_sharded_equals_single(va, oracle):
     assert np.array_equal(acc.cpu().numpy(), want)
 
 
+def test_kmeans_sharded_iter_two_shards_vs_oracle(va, oracle):
+    """The sharded loop's device path proper: dg_kmeans_iou_iter (centroid update folded into the next step's prologue)
+    on two shards of one device, their int64 sums added by hand (the all-reduce), against the oracle's fixed-iteration fit."""
+    from vision_amd import cluster
+    n, k, iters = 70001, 5, 6
+    wh = wl.anchor_wh(12, n)
+    init = oracle.kmeans_init(wh, k, 42)
+    cut = 26001                                   # odd: the second shard starts 8-byte- but not 16-byte-aligned
+    x = torch.from_numpy(wh).cuda()
+    shards = []
+    for lo, hi in ((0, cut), (cut, n)):
+        be = cluster._HipBackend()
+        be.prepare(x[lo:hi], init, k, iters)
+        shards.append(be)
+    for t in range(iters):
+        for be in shards:
+            be.iterate(t > 0, t + 1 == iters, t - 1)
+        total = shards[0].acc + shards[1].acc
+        for be in shards:
+            be.acc.copy_(total)
+    for be in shards:
+        be.update(iters - 1)
+    cent, labels, n_iter, inertia = oracle.kmeans_fit(wh, k, 42, fixed_iters=iters)
+    hist = None
+    for be, (lo, hi) in zip(shards, ((0, cut), (cut, n))):
+        c, l, acc = be.results()
+        assert np.array_equal(c, cent)
+        assert np.array_equal(l, labels[lo:hi])
+        assert abs(float(acc[3 * k + 1]) / 2.0 ** 32 - inertia) < 1e-9
+        h = be.history_host(iters)
+        assert hist is None or np.array_equal(h, hist)
+        hist = h
+    assert hist[0] == n                           # every label changes in the first iteration
+
+
+@pytest.mark.parametrize("graph", ["1", "0"])
+def test_kmeans_sharded_loop_single_rank_group_vs_oracle(va, oracle, graph, monkeypatch):
+    """kmean's sharded loop as the product runs it: launch + RCCL all-reduce per iteration (a single-rank group here: one
+    GPU), once captured in a HIP graph and once eager, to convergence and for a fixed count, against the oracle."""
+    import socket
+    import torch.distributed as dist
+    from vision_amd import cluster
+    monkeypatch.setenv("DG_KMEANS_GRAPH", graph)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        wh = wl.anchor_wh(5, 150001)
+        x = torch.from_numpy(wh).cuda()
+        km = cluster.kmean(5, 42, sharded=True).fit(x)
+        cent, labels, n_iter, inertia = oracle.kmeans_fit(wh, 5, 42)
+        assert np.array_equal(km.cluster_centers_, cent) and np.array_equal(km.labels_, labels)
+        assert km.n_iter_ == n_iter and abs(km.inertia_ - inertia) < 1e-9
+        assert km.graph_state == ("captured" if graph == "1" else "eager: graph capture disabled or host-side all-reduce"), km.graph_state
+        km3 = cluster.kmean(5, 42, sharded=True).fit(x, fixed_iters=11)
+        c3, l3, n3, i3 = oracle.kmeans_fit(wh, 5, 42, fixed_iters=11)
+        assert np.array_equal(km3.cluster_centers_, c3) and np.array_equal(km3.labels_, l3) and km3.n_iter_ == 11
+        km3._run_iters(0, 11)                     # replay (or eager re-run) continues the fit: 22 iterations
+        torch.cuda.synchronize()
+        c22, _, _, _ = oracle.kmeans_fit(wh, 5, 42, fixed_iters=22)
+        assert np.array_equal(km3._backend.cent.cpu().numpy(), c22)
+    finally:
+        dist.destroy_process_group()
+
+
 def _km_adversarial_boxes(seed, n, cent):
     """boxes that stress the assignment pre-filter: exact and near ties, tiny overlaps, copies of the centroids,
     zero-size, negative and very large boxes, next to ordinary ones."""

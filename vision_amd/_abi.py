@@ -46,6 +46,7 @@ SIGNATURES = {
     "dg_roipool_bwd_a16_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, C.c_int, _vp, _vp, _sz, _vp]),
     "dg_kmeans_workspace_bytes": (_sz, [_i64, _i64]),
     "dg_kmeans_iou_step": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
+    "dg_kmeans_iou_iter": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, C.c_int, C.c_int, _vp, _i64, _vp, _sz, _vp]),
     "dg_kmeans_update": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp]),
     "dg_kmeans_iou_run": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _sz, _vp]),
     "dg_kmeans_labels_i32": (C.c_int, [_vp, _i64, _vp, _vp]),
@@ -124,17 +125,25 @@ def ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
-# per-device scratch, grown on demand (the C ABI allocates nothing)
+# scratch, grown on demand (the C ABI allocates nothing).  One buffer per (device, stream): calls in flight on different
+# streams must not share masks, tickets or RoI lists.  A buffer is allocated while its stream
+# is current, so the caching allocator hands a replaced buffer's memory out again only in that stream's order.
 _ws = {}
+_WS_MAX_ENTRIES = 64
 
 
 def workspace(device, nbytes):
-    key = (device.type, device.index)
+    stream = torch.cuda.current_stream(device)
+    key = (device.index, stream.cuda_stream)
     buf = _ws.get(key)
     if buf is None or buf.numel() < nbytes:
-        buf = None
-        _ws.pop(key, None)
-        buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
+        if buf is not None:
+            buf.record_stream(stream)            # kernels already queued on this stream may still be using it
+        if len(_ws) >= _WS_MAX_ENTRIES:          # streams come and go: do not keep their buffers for ever
+            for k in [k for k in _ws if k != key]:
+                _ws.pop(k)                       # its memory returns to the allocator in its own stream's order
+        with torch.cuda.device(device):
+            buf = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=device)
         _ws[key] = buf
     return buf
 

@@ -3,10 +3,13 @@
 
 The reference itself runs sklearn's Euclidean KMeans on a toy table; the 1-IoU Lloyd iteration is
 build-defined (spec: oracle/oracle.c) and therefore "parity unpinned".
-Multi-GPU: every rank holds a contiguous shard of the boxes; per iteration one all-reduce of the
-(3k+2) int64 accumulator (RCCL over xGMI via torch.distributed); integer sums make the result
-bit-identical for every world size.
+Multi-GPU: every rank holds a contiguous shard of the boxes; per iteration ONE launch (the centroid
+update is the prologue of the next step, dg_kmeans_iou_iter) and ONE all-reduce of the (3k+2) int64
+accumulator (RCCL over xGMI via torch.distributed); a chunk of iterations is captured in a HIP graph
+when the process group allows it.  Integer sums make the result bit-identical for every world size.
 """
+import os
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -26,24 +29,35 @@ class _HipBackend:
         self.labels = torch.full((self.wh.shape[0],), 255, dtype=torch.uint8, device=dev)
         self.acc = torch.zeros(3 * k + 2, dtype=torch.int64, device=dev)
         self.history = torch.zeros(max(iters, 1), dtype=torch.int64, device=dev)
+        # the launch ticket lives in the workspace across the calls of a chunk: this loop owns its workspace
+        self.ws_bytes = _abi.load().dg_kmeans_workspace_bytes(self.wh.shape[0], k)
+        self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
         self._bound = None
 
     def run_local(self, slot0, iters):
-        ops.kmeans_run(self.wh, self.cent, self.labels, self.acc, self.history, slot0, iters)
+        """single device: `iters` launches issued by one C call (dg_kmeans_iou_run)"""
+        dev = self.wh.device
+        with torch.cuda.device(dev):
+            _abi.check(_abi.load().dg_kmeans_iou_run(_abi.ptr(self.wh), self.wh.shape[0], _abi.ptr(self.cent), self.cent.shape[0],
+                                                     _abi.ptr(self.labels), _abi.ptr(self.acc), _abi.ptr(self.history), slot0, iters,
+                                                     _abi.ptr(self.ws), self.ws_bytes, _abi.stream_ptr(dev)))
 
-    # The sharded loop calls step / all-reduce / update once per iteration from Python: with the kernels at a few
-    # microseconds per shard the host side is the bottleneck, so the ABI calls are bound once with raw pointers.
+    # The sharded loop issues one launch + one all-reduce per iteration from Python: with the kernel at a few microseconds
+    # per shard the host side matters, so the ABI calls are bound once with raw pointers.
     def _bind(self):
         lib = _abi.load()
         dev = self.wh.device
         n, k = self.wh.shape[0], self.cent.shape[0]
-        nbytes = lib.dg_kmeans_workspace_bytes(n, k)
-        self._ws = _abi.workspace(dev, nbytes)
         st = _abi.stream_ptr(dev)
-        a = (_abi.ptr(self.wh), n, _abi.ptr(self.cent), k, _abi.ptr(self.labels), _abi.ptr(self.acc), _abi.ptr(self._ws), nbytes, st)
-        u = (_abi.ptr(self.acc), k, _abi.ptr(self.cent), _abi.ptr(self.history))
-        step_fn, upd_fn, check = lib.dg_kmeans_iou_step, lib.dg_kmeans_update, _abi.check
-        self._bound = (dev, st.value, lambda: check(step_fn(*a)), lambda slot: check(upd_fn(*u, slot, st)))
+        head = (_abi.ptr(self.wh), n, _abi.ptr(self.cent), k, _abi.ptr(self.labels), _abi.ptr(self.acc))
+        tail = (_abi.ptr(self.ws), self.ws_bytes, st)
+        hist = _abi.ptr(self.history)
+        u = (_abi.ptr(self.acc), k, _abi.ptr(self.cent), hist)
+        step_fn, iter_fn, upd_fn, check = lib.dg_kmeans_iou_step, lib.dg_kmeans_iou_iter, lib.dg_kmeans_update, _abi.check
+        self._bound = (dev, st.value,
+                       lambda: check(step_fn(*head, *tail)),
+                       lambda slot: check(upd_fn(*u, slot, st)),
+                       lambda apply_prev, inertia, slot: check(iter_fn(*head, apply_prev, inertia, hist, slot, *tail)))
 
     def _fast(self):
         b = getattr(self, "_bound", None)
@@ -53,12 +67,19 @@ class _HipBackend:
         return b
 
     def step(self):
+        """plain step: acc <- this shard's sums (with the inertia), centroids untouched"""
         with torch.cuda.device(self.wh.device):
             self._fast()[2]()
 
     def update(self, slot):
         with torch.cuda.device(self.wh.device):
             self._fast()[3](slot)
+
+    def iterate(self, apply_prev, inertia, slot):
+        """one sharded iteration as one launch: [centroids <- previous all-reduced acc; history[slot] <- its changed
+        count;] step; acc <- this shard's sums"""
+        with torch.cuda.device(self.wh.device):
+            self._fast()[4](int(apply_prev), int(inertia), slot)
 
     def history_host(self, upto):
         return self.history[:upto].cpu().numpy()
@@ -68,13 +89,18 @@ class _HipBackend:
 
 
 class kmean:
-    def __init__(self, n_clusters=5, random_state=42, max_iter=300, group=None, reduce_device=None):
+    def __init__(self, n_clusters=5, random_state=42, max_iter=300, group=None, reduce_device=None, sharded=None):
+        """sharded: None = the sharded loop iff the process group has more than one rank; True forces it (with a
+        single-rank group it then runs launch + all-reduce per iteration, which is how its device path is tested)."""
         if not 1 <= n_clusters <= 16:
             raise ValueError("n_clusters must be in [1,16]")
         self.n_clusters, self.random_state, self.max_iter = n_clusters, random_state, max_iter
         self.group = group
         self.reduce_device = reduce_device      # all-reduce on another device (e.g. "cpu" with gloo)
+        self.sharded = sharded
         self._backend = _HipBackend()
+        self._graphs = {}
+        self.graph_state = "unused"             # "captured" / "eager: <why>" once the sharded loop has run
         self.cluster_centers_ = None
         self.labels_ = None
         self.n_iter_ = 0
@@ -84,8 +110,11 @@ class kmean:
     def _world(self):
         return dist.get_world_size(self.group) if (dist.is_available() and dist.is_initialized()) else 1
 
+    def _is_sharded(self):
+        return self._world() > 1 if self.sharded is None else bool(self.sharded)
+
     def _allreduce(self, acc):
-        if self._world() == 1:
+        if not (dist.is_available() and dist.is_initialized()):
             return
         if self.reduce_device is not None:
             t = acc.to(self.reduce_device)
@@ -113,36 +142,68 @@ class kmean:
             init_centers = self.init_centers(src, k, self.random_state)
         iters = fixed_iters if fixed_iters is not None else self.max_iter
         be = self._backend
-        be.prepare(X, init_centers, k, iters)
+        self._graphs = {}
+        be.prepare(X, init_centers, k, min(iters, _CHUNK) if fixed_iters is None else iters)
         done, n_iter = 0, 0
         while done < iters:
             chunk = min(_CHUNK if fixed_iters is None else iters, iters - done)
             # a converged iteration (changed == 0) recomputes identical centroids, so running the
-            # rest of the chunk is idempotent; n_iter_ is read from the history afterwards.
-            self._run_iters(done, chunk)
+            # rest of the chunk is idempotent; every chunk writes history[0:chunk], read back here.
+            self._run_iters(0, chunk)
+            if fixed_iters is None:
+                z = np.nonzero(be.history_host(chunk) == 0)[0]
+                if z.size:
+                    n_iter = done + int(z[0]) + 1
+                    break
             done += chunk
             n_iter = done
-            if fixed_iters is None:
-                z = np.nonzero(be.history_host(done) == 0)[0]
-                if z.size:
-                    n_iter = int(z[0]) + 1
-                    break
         cent, labels, acc = be.results()
         self.cluster_centers_, self.labels_ = cent, labels
         self.n_iter_ = n_iter
         self.inertia_ = float(acc[3 * k + 1]) / 4294967296.0
         return self
 
-    def _run_iters(self, slot0, count):
-        """`count` Lloyd iterations, asynchronous on the current stream (history slots slot0..)."""
+    def _sharded_chunk(self, slot0, count):
+        """count iterations: [launch, all-reduce] x count, then the last update.  The inertia is formed by the
+        chunk's last launch only, exactly as dg_kmeans_iou_run does on a single device."""
         be = self._backend
-        if self._world() == 1:
+        for j in range(count):
+            be.iterate(j > 0, j + 1 == count, slot0 + j - 1)
+            self._allreduce(be.acc)
+        be.update(slot0 + count - 1)
+
+    def _run_iters(self, slot0, count):
+        """`count` Lloyd iterations, asynchronous on the current stream (history slots slot0..slot0+count-1)."""
+        be = self._backend
+        if not self._is_sharded():
             be.run_local(slot0, count)
-        else:
-            for j in range(count):
-                be.step()
-                self._allreduce(be.acc)
-                be.update(slot0 + j)
+            return
+        # HIP graph of the whole chunk (kernels + RCCL all-reduces): replays cost the host one launch.  Only when the
+        # all-reduce runs on the device (not the gloo rehearsal path) and DG_KMEANS_GRAPH != 0; any capture failure
+        # falls back to eager launches for the rest of this fit.
+        use_graph = (self.reduce_device is None and be.acc.is_cuda and os.environ.get("DG_KMEANS_GRAPH", "1") != "0"
+                     and not str(self.graph_state).startswith("eager"))
+        if not use_graph:
+            if self.graph_state == "unused":
+                self.graph_state = "eager: graph capture disabled or host-side all-reduce"
+            self._sharded_chunk(slot0, count)
+            return
+        key = (slot0, count, be.wh.data_ptr())
+        g = self._graphs.get(key)
+        if g is None:
+            self._sharded_chunk(slot0, count)            # warm-up outside capture (RCCL channels, occupancy look-ups)
+            try:
+                torch.cuda.synchronize(be.wh.device)
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._sharded_chunk(slot0, count)
+                self._graphs[key] = g
+                self.graph_state = "captured"
+            except Exception as e:  # noqa: BLE001  (capture of a collective is backend-dependent)
+                self.graph_state = f"eager: capture failed ({type(e).__name__}: {e})"
+                be._bound = None
+            return                                        # the warm-up run WAS this chunk
+        g.replay()
 
     def fit_predict(self, X, **kw):
         return self.fit(X, **kw).labels_

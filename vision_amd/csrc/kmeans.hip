@@ -124,10 +124,27 @@ __device__ __forceinline__ void km_one(float w, float h, const float (&cw)[KMAX]
 // INERTIA = false (the iterations of dg_kmeans_iou_run before its last): the sum of distances is not formed, so the
 // winner's exact distance is not evaluated either; acc[3k+1] is then written as 0.  A Lloyd iteration needs the sums,
 // the counts and the changed count; the inertia is reported for the final assignment only (as sklearn does).
+// mode: KM_MODE_STEP  plain step: acc <- this shard's sums, centroids untouched;
+//       KM_MODE_RUN   single-device loop: the last workgroup also moves the centroids by this launch's sums and
+//                     writes history[slot] = this iteration's changed count;
+//       KM_MODE_APPLY sharded loop: `acc` arrives holding the ALL-REDUCED sums of the previous iteration; every
+//                     workgroup first derives this iteration's centroids from (cent, acc) -- the centroid update is the
+//                     prologue of the next step, so an iteration is ONE launch + ONE all-reduce -- and the last
+//                     workgroup writes those centroids back to `cent`, history[slot] = the previous iteration's changed
+//                     count, and acc <- this shard's sums.  In-place is safe: a workgroup draws its ticket after its
+//                     last use of cent / acc, and only the drawer of the last ticket writes them.
+#define KM_MODE_STEP 0
+#define KM_MODE_RUN 1
+#define KM_MODE_APPLY 2
+__device__ __forceinline__ float km_centroid(long long sum, long long cnt)      // as k_kmeans_update / orc_kmeans_update
+{
+    return (float)((double)sum / (double)cnt / 4294967296.0);
+}
+
 template <int KMAX, bool FULL, bool INERTIA>
-__global__ __launch_bounds__(KM_BLOCK) void k_kmeans_step(const float2 *__restrict__ wh, int64_t n, const float *cent, int k,
+__global__ __launch_bounds__(KM_BLOCK) void k_kmeans_step(const float2 *__restrict__ wh, int64_t n, float *cent, int k,
                                                           uint8_t *__restrict__ labels, long long *partials, unsigned *ticket,
-                                                          long long *__restrict__ acc, float *cent_out, long long *__restrict__ history,
+                                                          long long *acc, int mode, long long *__restrict__ history,
                                                           int64_t slot)
 {
     constexpr int COLS = 3 * KMAX + 2, CP = (COLS + 1) & ~1;      // a row is padded to whole 16-byte pairs
@@ -135,19 +152,30 @@ __global__ __launch_bounds__(KM_BLOCK) void k_kmeans_step(const float2 *__restri
     __shared__ unsigned scnt_all[KMAX * KM_BLOCK];
     __shared__ long long red[KM_BLOCK / 64][3 * KMAX + 2];
     __shared__ float2 scent[16];
+    __shared__ long long s_prev_changed;
     const int tid = threadIdx.x;
+    if (tid < 16) {
+        float2 c = (tid < k) ? make_float2(cent[2 * tid], cent[2 * tid + 1]) : make_float2(0.f, 0.f);
+        if (mode == KM_MODE_APPLY && tid < k) {
+            const long long cnt = acc[2 * k + tid];
+            if (cnt > 0) { c.x = km_centroid(acc[tid], cnt); c.y = km_centroid(acc[k + tid], cnt); }
+        }
+        scent[tid] = c;
+        if (tid == 0) s_prev_changed = (mode == KM_MODE_APPLY) ? acc[3 * k] : 0;
+    }
+    __syncthreads();
     float cw[KMAX], ch[KMAX];
     bool cent_ok = true;
 #pragma unroll
     for (int c = 0; c < KMAX; ++c) {
-        cw[c] = (c < k) ? cent[2 * c] : 0.f;
-        ch[c] = (c < k) ? cent[2 * c + 1] : 0.f;
+        // wave-uniform values: back into scalar registers
+        cw[c] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(scent[c < 16 ? c : 0].x)));
+        ch[c] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(scent[c < 16 ? c : 0].y)));
         cent_ok = cent_ok && (fabsf(cw[c] * ch[c]) < 0x1p60f);
         sacc_all[(c * 2 + 0) * KM_BLOCK + tid] = 0;
         sacc_all[(c * 2 + 1) * KM_BLOCK + tid] = 0;
         scnt_all[c * KM_BLOCK + tid] = 0;
     }
-    if (tid < 16) scent[tid] = (tid < k) ? make_float2(cent[2 * tid], cent[2 * tid + 1]) : make_float2(0.f, 0.f);
     __syncthreads();
     const unsigned gap_min = cent_ok ? KM_GAP_MIN : 0xffffffffu;     // a gap nobody reaches: exact path only
     unsigned long long *sacc = sacc_all + tid;     // lane-private column: no barrier needed until the final reduce
@@ -314,15 +342,18 @@ __global__ __launch_bounds__(KM_BLOCK) void k_kmeans_step(const float2 *__restri
         if (grp < 3) { if (c < k) acc[grp * k + c] = t; }
         else acc[3 * k + c] = t;                           // changed, inertia
     }
-    if (cent_out) {                                        // same arithmetic as k_kmeans_update
+    if (mode == KM_MODE_RUN) {                             // same arithmetic as k_kmeans_update
         if (tid < k) {
             const long long cnt = (long long)s_tot[2 * KMAX + tid];
             if (cnt > 0) {
-                cent_out[2 * tid] = (float)((double)(long long)s_tot[tid] / (double)cnt / 4294967296.0);
-                cent_out[2 * tid + 1] = (float)((double)(long long)s_tot[KMAX + tid] / (double)cnt / 4294967296.0);
+                cent[2 * tid] = km_centroid((long long)s_tot[tid], cnt);
+                cent[2 * tid + 1] = km_centroid((long long)s_tot[KMAX + tid], cnt);
             }
         }
         if (tid == 0 && history) history[slot] = (long long)s_tot[3 * KMAX];
+    } else if (mode == KM_MODE_APPLY) {                    // the centroids this launch derived and used
+        if (tid < k) { cent[2 * tid] = scent[tid].x; cent[2 * tid + 1] = scent[tid].y; }
+        if (tid == 0 && history) history[slot] = s_prev_changed;
     }
     if (tid == 0) *ticket = 0;
 }
@@ -376,7 +407,7 @@ extern "C" size_t dg_kmeans_workspace_bytes(int64_t n, int64_t k)
 static inline unsigned *km_ticket(void *ws) { return (unsigned *)((char *)ws + (size_t)KM_MAXBLOCKS * (3 * 16 + 2) * 8); }
 
 // step (+ fold) as one launch; with cent_out the last workgroup also writes the new centroids and history[slot]
-static int km_launch(const float *wh, int64_t n, const float *cent, int64_t k, uint8_t *labels, int64_t *acc, float *cent_out,
+static int km_launch(const float *wh, int64_t n, float *cent, int64_t k, uint8_t *labels, int64_t *acc, int mode,
                      int64_t *history, int64_t slot, bool inertia, void *ws, hipStream_t st)
 {
     const int kmax = km_kmax(k);
@@ -385,7 +416,7 @@ static int km_launch(const float *wh, int64_t n, const float *cent, int64_t k, u
     do {                                                                                                                        \
         static const int resident = km_resident_blocks(k_kmeans_step<KM, FULL, INERTIA>);                                       \
         hipLaunchKernelGGL((k_kmeans_step<KM, FULL, INERTIA>), dim3(km_blocks(n, resident)), dim3(KM_BLOCK), 0, st,             \
-                           (const float2 *)wh, n, cent, (int)k, labels, partials, km_ticket(ws), (long long *)acc, cent_out,    \
+                           (const float2 *)wh, n, cent, (int)k, labels, partials, km_ticket(ws), (long long *)acc, mode,        \
                            (long long *)history, slot);                                                                         \
     } while (0)
 #define KM_LAUNCH(KM, FULL)                                                                                                     \
@@ -424,7 +455,27 @@ extern "C" int dg_kmeans_iou_step(const float *wh, int64_t n, const float *cent,
     hipStream_t st = (hipStream_t)s;
     // the workspace arrives with arbitrary contents
     if (hipMemsetAsync(km_ticket(ws), 0, 16, st) != hipSuccess) { dg_set_error("kmeans_step: memset failed"); return DG_EHIP; }
-    return km_launch(wh, n, cent, k, labels, acc, nullptr, nullptr, 0, true, ws, st);
+    return km_launch(wh, n, const_cast<float *>(cent), k, labels, acc, KM_MODE_STEP, nullptr, 0, true, ws, st);
+}
+
+// One iteration of the SHARDED Lloyd loop as one launch (KM_MODE_APPLY above).  apply_prev != 0: acc holds the
+// all-reduced sums of the previous iteration; the centroids are first moved by them (empty cluster keeps its centroid),
+// written back to `cent`, and history[slot] (may be NULL) receives the previous iteration's changed count.  Then the
+// step runs and acc is overwritten with this shard's sums: all-reduce it and call again.  After the last iteration,
+// dg_kmeans_update applies the last sums.  want_inertia == 0 leaves acc[3k+1] = 0 (a Lloyd iteration does not use it).
+// A call with apply_prev != 0 must follow another dg_kmeans_iou_iter call on the same workspace, stream-ordered, with
+// nothing else using that workspace in between (the launch ticket in it is cleared by apply_prev == 0 calls only).
+extern "C" int dg_kmeans_iou_iter(const float *wh, int64_t n, float *cent, int64_t k, uint8_t *labels, int64_t *acc,
+                                  int apply_prev, int want_inertia, int64_t *history, int64_t slot, void *ws,
+                                  size_t ws_bytes, dg_stream_t s)
+{
+    int rc = km_check(wh, n, cent, k, labels, acc, ws, ws_bytes);
+    if (rc) return rc;
+    hipStream_t st = (hipStream_t)s;
+    // the ticket returns to zero at the end of every launch: only the first call of a sequence has to clear it
+    if (!apply_prev && hipMemsetAsync(km_ticket(ws), 0, 16, st) != hipSuccess) { dg_set_error("kmeans_iter: memset failed"); return DG_EHIP; }
+    return km_launch(wh, n, cent, k, labels, acc, apply_prev ? KM_MODE_APPLY : KM_MODE_STEP, apply_prev ? history : nullptr,
+                     slot, want_inertia != 0, ws, st);
 }
 
 extern "C" int dg_kmeans_update(const int64_t *acc, int64_t k, float *cent, int64_t *history, int64_t slot, dg_stream_t s)
@@ -449,7 +500,7 @@ extern "C" int dg_kmeans_iou_run(const float *wh, int64_t n, float *cent, int64_
     hipStream_t st = (hipStream_t)s;
     if (hipMemsetAsync(km_ticket(ws), 0, 16, st) != hipSuccess) { dg_set_error("kmeans_run: memset failed"); return DG_EHIP; }
     for (int64_t t = 0; t < iters; ++t) {
-        rc = km_launch(wh, n, cent, k, labels, acc, cent, history, slot0 + t, t + 1 == iters, ws, st);   // inertia: last only
+        rc = km_launch(wh, n, cent, k, labels, acc, KM_MODE_RUN, history, slot0 + t, t + 1 == iters, ws, st);   // inertia: last only
         if (rc) return rc;
     }
     return DG_OK;
