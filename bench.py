@@ -1,11 +1,16 @@
 #!/usr/bin/env python3
 """bench.py — box-geometry hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
 
-Primary line (ONE JSON line on rank 0): BASELINE.json configs[2] — Fast R-CNN batch of 256 images x
-2000 RoIs on 512x38x50 maps: RoI max-pool forward (+argmax), backward, and batched NMS (thr 0.7),
-sharded by image over the ranks with no data-path collective (total work fixed => "strong").
+With N > 1 and no WORLD_SIZE in the environment this process starts the N ranks itself (a
+`python -m torch.distributed.run` child, decided before any GPU call) and exits with the child's code; under
+torchrun (WORLD_SIZE set) it is one of the ranks.  A line whose n_gpus differs from --gpus is never printed.
+
+Primary line (ONE JSON line on rank 0): BASELINE.json configs[2] — Fast R-CNN batch of 256 images x 2000 RoIs on
+512x38x50 maps: RoI max-pool forward (+argmax), backward, and batched NMS (thr 0.7).  The path shards by image with
+no data-path collective; every rank processes a full 256-image batch ("weak": per-GPU work fixed; `--scaling strong`
+splits ONE 256-image batch over the ranks instead, and N > 1 runs report that as extra.config3_strong_scaling).
 A "step" is one pass of that hot path over the batch; value = RoIs processed by all ranks / time.
 `roofline` prices the dominant kernel (k_roipool_fwd) against 8 TB/s HBM; `cpu_baseline` times the
 CPU oracle (a port of the reference's algorithm) on a bounded sample on rank 0.
@@ -31,8 +36,11 @@ ROI_BYTES_A16 = 150528            # the uint16-argmax layout slowroipool's autog
 MAP_BYTES = 3891200               # one 512x38x50 fp32 map
 
 
+VALU_PEAK_LANE_OPS = 256 * 4 * 32 * 2.4e9   # MI355X_MICROARCH.md: 256 CUs x 4 SIMD-32 at 2.4 GHz = 7.86e13 lane-ops/s (157.3 TFLOP/s fp32 = 2 flops each)
+
+
 def ev_time(fn, iters, warm=1):
-    """median-free mean of `iters` runs timed with HIP events on the current stream (ms)."""
+    """mean of `iters` back-to-back runs timed with one HIP event pair on the current stream (ms)."""
     for _ in range(warm):
         fn()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -44,28 +52,73 @@ def ev_time(fn, iters, warm=1):
     return a.elapsed_time(b) / iters
 
 
+def ev_median(fn, iters=50, warm=20):
+    """20 warm-up + median of >= 50 launches, each bracketed by its own HIP event pair on the launch stream (ms)."""
+    for _ in range(warm):
+        fn()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    t = sorted(a.elapsed_time(b) for a, b in evs)
+    return t[len(t) // 2]
+
+
+def free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a torch.distributed.run child (this process has
+    made no GPU call) and hand back its exit code; the ranks' stdout/stderr are this process's."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    print(f"[bench] --gpus {n} without WORLD_SIZE: starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.call(cmd)
+
+
 class Dist:
-    def __init__(self, n):
+    def __init__(self, n, stub=False):
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local = int(os.environ.get("LOCAL_RANK", "0"))
-        if self.world != n and self.world > 1:
-            raise SystemExit(f"--gpus {n} but WORLD_SIZE={self.world}")
+        if self.world != n:
+            raise SystemExit(f"bench.py: --gpus {n} but WORLD_SIZE={self.world}: refusing to report a run whose n_gpus differs from --gpus")
         # DG_BENCH_REHEARSE=1: every rank on cuda:0 with gloo -- a functional rehearsal of the N>1 path on a one-GPU box
-        rehearse = self.rehearse = os.environ.get("DG_BENCH_REHEARSE") == "1"
-        dev_index = 0 if rehearse else self.local
-        torch.cuda.set_device(dev_index)
-        self.dev = torch.device("cuda", dev_index)
+        # stub (DG_BENCH_STUB=1): no GPU at all, gloo -- exercises the launch / timing / reporting scaffolding on the CPU
+        rehearse = self.rehearse = stub or os.environ.get("DG_BENCH_REHEARSE") == "1"
+        self.stub = stub
+        self.backend = "none"
+        if stub:
+            self.dev = torch.device("cpu")
+        else:
+            dev_index = 0 if rehearse else self.local
+            torch.cuda.set_device(dev_index)
+            self.dev = torch.device("cuda", dev_index)
         if self.world > 1:
+            self.backend = "gloo" if rehearse else "nccl"
             if rehearse:
                 dist.init_process_group("gloo")
             else:
                 dist.init_process_group("nccl", device_id=self.dev)
+            seen = dist.get_world_size()
+            if seen != n:
+                raise SystemExit(f"bench.py: process group has {seen} ranks, --gpus {n}")
+            print(f"[bench rank {self.rank}] process group up: backend={self.backend} world_size={seen} device={self.dev}", file=sys.stderr, flush=True)
 
     def barrier(self):
         if self.world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not self.stub:
+            torch.cuda.synchronize()
 
     def max(self, x):
         if self.world == 1:
@@ -87,7 +140,7 @@ class Dist:
 
 # ------------------------------------------------------------------ config 3 (primary) / config 1
 class FrcnnBatch:
-    def __init__(self, d, images_total, n_rois=2000, C=512, H=38, W=50, nms_thr=0.7):
+    def __init__(self, d, images_total, n_rois=2000, C=512, H=38, W=50, nms_thr=0.7, roi_gen=None):
         from vision_amd import ops, shard
         from tools import workloads as wl
         self.ops, self.d = ops, d
@@ -97,7 +150,8 @@ class FrcnnBatch:
         dev = d.dev
         g = torch.Generator(device=dev).manual_seed(1234 + d.rank)
         self.img = torch.randn((per, C, H, W), generator=g, device=dev, dtype=torch.float32)
-        rois = np.concatenate([wl.frcnn_rois(first + i, n_rois) for i in range(per)])
+        roi_gen = roi_gen or wl.frcnn_rois
+        rois = np.concatenate([roi_gen(first + i, n_rois) for i in range(per)])
         self.rois = torch.from_numpy(rois).to(dev)
         self.idx = torch.arange(per, device=dev, dtype=torch.int64).repeat_interleave(n_rois)
         self.boxes = self.rois.to(torch.float32).reshape(per, n_rois, 4).contiguous()
@@ -157,8 +211,32 @@ def cpu_baseline_frcnn(images=12, n_rois=2000):
         b, s = wl.frcnn_proposals(i, n_rois)
         orc.nms(b, s, 0.7)
     dt = time.perf_counter() - t0
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count()
     return {"value": images * n_rois / dt, "unit": "RoIs/s", "cores": 1, "kind": "port",
-            "sample": f"{images} images x {n_rois} RoIs of the same step (C oracle: RoI max-pool fwd+bwd + NMS 0.7), {dt:.1f} s"}
+            "host": {"os_cpu_count": os.cpu_count(), "usable_cpus": usable, "torch_num_threads": torch.get_num_threads()},
+            "sample": f"{images} images x {n_rois} RoIs of the same step (C oracle: RoI max-pool fwd+bwd + NMS 0.7), {dt:.1f} s, "
+                      "single thread; the reference's own Python is timed in the build container only (BASELINE.md section 2, "
+                      "tools/time_reference_cpu.py): it cannot travel to the GPU box"}
+
+
+def counters():
+    """per-launch PMC figures summarised from profiles/ (tools/pmc_summary.py): {kernel: {size: {...}}}"""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    except Exception:  # noqa: BLE001
+        return {}
+
+
+def valu_frac(kernel, size, ms):
+    """VALU lane-operations per second of a launch (SQ_INSTS_VALU x 64 lanes, from the committed PMC pass) over the chip's
+    VALU issue peak: the yardstick for the kernels that are VALU-bound, where an HBM fraction says nothing."""
+    insts = counters().get("valu_insts_per_launch", {}).get(kernel, {}).get(str(size))
+    if not insts:
+        return None
+    return insts * 64.0 / (ms * 1e-3) / VALU_PEAK_LANE_OPS
 
 
 # ------------------------------------------------------------------ extras
@@ -166,17 +244,17 @@ def extra_single_image(d):
     w = FrcnnBatch(d if d.world == 1 else _solo(d), 1)
     w.windows(); w.stage()
     r = {}
-    t = ev_time(w.fwd, 20, 3); r["roipool_fwd_ms"] = t
+    t = ev_median(w.fwd, 100, 20); r["roipool_fwd_ms"] = t
     r["roipool_fwd_rois_per_s"] = 2000 / t * 1e3
     r["roipool_fwd_hbm_frac"] = (2000 * ROI_BYTES + MAP_BYTES) / (t * 1e-3) / 1e9 / HBM_PEAK_GBPS
-    t = ev_time(w.bwd, 20, 3); r["roipool_bwd_ms"] = t
+    t = ev_median(w.bwd, 100, 20); r["roipool_bwd_ms"] = t
     r["roipool_bwd_hbm_frac"] = (2000 * ROI_BYTES + MAP_BYTES) / (t * 1e-3) / 1e9 / HBM_PEAK_GBPS
     for thr in (0.7, 0.3):
         w.nms_thr = thr
-        t = ev_time(w.nms, 20, 3)
+        t = ev_median(w.nms, 100, 20)
         r[f"nms2000_thr{thr}_ms"] = t
         r[f"nms2000_thr{thr}_boxes_per_s"] = 2000 / t * 1e3
-    r["note"] = "config 1; NMS at N=2000 is launch-latency-bound (3 kernels)"
+    r["note"] = "config 1; NMS at N=2000 is launch-latency-bound (6 kernels); median of 100 launches after 20 warm-up"
     return r
 
 
@@ -186,18 +264,41 @@ class _solo:
         self.world, self.rank, self.dev = 1, 0, d.dev
 
 
+def extra_wide_rois(d, images=32):
+    """RoI pooling on a proposal mix with no size bound (w,h ~ U(0.1,0.9) of the map: crops up to 46 x 35 cells): the
+    primary workload's RoIs (w,h ~ U(0.02,0.30)) are at most 16 cells wide."""
+    from tools import workloads as wl
+    w = FrcnnBatch(_solo(d), images, roi_gen=wl.frcnn_rois_wide)
+    w.windows(); w.stage()
+    tf, tb = ev_median(w.fwd, 20, 5), ev_median(w.bwd, 20, 5)
+    w.check()
+    by = w.n * ROI_BYTES + w.B * MAP_BYTES
+    return {"images": images, "rois": w.n, "roipool_fwd_ms": tf, "roipool_bwd_ms": tb,
+            "fwd_rois_per_s": w.n / tf * 1e3, "bwd_rois_per_s": w.n / tb * 1e3,
+            "fwd_hbm_frac": by / (tf * 1e-3) / 1e9 / HBM_PEAK_GBPS, "bwd_hbm_frac": by / (tb * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "note": "output bytes per RoI are the same as in the primary workload; a wide crop reads up to 1610 cells x 512 ch "
+                    "(3.3 MB, from L2) per 200 KB written, so this mix is bound by the argmax scan, not by HBM"}
+
+
 def extra_yolo(d):
-    from vision_amd import yolo_v1
+    from vision_amd import yolo_v1, ops
     from tools import workloads as wl
     out, tgt = wl.yolo1_batch(0, 64)
     o, t = torch.from_numpy(out).to(d.dev), torch.from_numpy(tgt).to(d.dev)
-    ms = ev_time(lambda: yolo_v1.decode_nms_batched(o, t, 0.2, 0.01, 0.3), 50, 5)
-    from vision_amd import ops
-    ms_loss = ev_time(lambda: ops.yolo1_loss(o, t, True, True), 50, 5)
-    return {"decode_nms_b64_ms": ms, "boxes_per_s": 64 * 98 / ms * 1e3,
-            "loss_fwd_bwd_b64_ms": ms_loss, "loss_cells_per_s": 64 * 49 / ms_loss * 1e3,
-            "note": "config 2: 4 kernels, ~0.4 MB moved: launch-latency-bound; NMS is class-agnostic per image as in the reference; "
-                    "loss = fused YOLOv1 loss forward + gradient (2 kernels; the reference issues ~60 torch kernels + autograd)"}
+    ms = ev_median(lambda: yolo_v1.decode_nms_batched(o, t, 0.2, 0.01, 0.3), 100, 20)
+    ms_loss = ev_median(lambda: ops.yolo1_loss(o, t, True, True), 100, 20)
+    r = {"decode_nms_b64_ms": ms, "boxes_per_s": 64 * 98 / ms * 1e3,
+         "loss_fwd_bwd_b64_ms": ms_loss, "loss_cells_per_s": 64 * 49 / ms_loss * 1e3,
+         "note": "config 2: ~0.4 MB moved: launch-latency-bound; NMS here is class-agnostic per image as in the reference "
+                 "(yolo.py:282-298 splits by class AFTER the NMS); loss = fused YOLOv1 loss forward + gradient (2 kernels; the "
+                 "reference issues ~60 torch kernels + autograd)"}
+    if hasattr(yolo_v1, "decode_nms_batched") and "per_class" in yolo_v1.decode_nms_batched.__code__.co_varnames:
+        ms_pc = ev_median(lambda: yolo_v1.decode_nms_batched(o, t, 0.2, 0.01, 0.3, per_class=True), 100, 20)
+        r["config2_per_class"] = {"decode_nms_b64_ms": ms_pc, "boxes_per_s": 64 * 98 / ms_pc * 1e3,
+                                  "note": "BASELINE configs[1] as worded: per-class NMS (boxes of different classes never suppress each "
+                                          "other).  No reference counterpart (the reference's NMS is class-agnostic): parity unpinned, "
+                                          "checked against the oracle's NMS applied per class"}
+    return r
 
 
 def extra_stress(d, n=65536):
@@ -207,7 +308,7 @@ def extra_stress(d, n=65536):
     b, s = wl.stress_boxes(0, n, dense=False)
     bt, st = torch.from_numpy(b).to(d.dev), torch.from_numpy(s).to(d.dev)
     out = torch.empty((n, n), dtype=torch.float32, device=d.dev)
-    ms = ev_time(lambda: ops.iou_pairwise(bt, bt, out=out), 5, 2)
+    ms = ev_median(lambda: ops.iou_pairwise(bt, bt, out=out), 50, 20)
     r["pairwise_64k_ms"] = ms
     r["pairwise_pairs_per_s"] = n * n / ms * 1e3
     r["pairwise_hbm_frac"] = (4.0 * n * n + 32 * n) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS
@@ -222,14 +323,17 @@ def extra_stress(d, n=65536):
         sp = _abi.stream_ptr(d.dev)
         for thr in (0.5, 0.7):
             tag = f"nms64k_{'dense' if dense else 'sparse'}_thr{thr}"
-            t_sort = ev_time(lambda: lib.dg_nms_phase_sort(_abi.ptr(bt), _abi.ptr(st), None, 1, n, _abi.ptr(ws), nb, sp), 5, 1)
-            t_mask = ev_time(lambda: lib.dg_nms_phase_mask(None, 1, n, thr, _abi.ptr(ws), nb, sp), 5, 1)
-            t_red = ev_time(lambda: lib.dg_nms_phase_reduce(None, 1, n, 1, _abi.ptr(keep), _abi.ptr(kc), _abi.ptr(ws), nb, sp), 3, 1)
+            t_sort = ev_median(lambda: lib.dg_nms_phase_sort(_abi.ptr(bt), _abi.ptr(st), None, 1, n, _abi.ptr(ws), nb, sp), 50, 20)
+            t_mask = ev_median(lambda: lib.dg_nms_phase_mask(None, 1, n, thr, _abi.ptr(ws), nb, sp), 50, 20)
+            t_red = ev_median(lambda: lib.dg_nms_phase_reduce(None, 1, n, 1, _abi.ptr(keep), _abi.ptr(kc), _abi.ptr(ws), nb, sp), 50, 20)
             tot = t_sort + t_mask + t_red
             r[tag] = {"sort_ms": t_sort, "mask_ms": t_mask, "reduce_ms": t_red, "kept": int(kc.item()),
                       "boxes_per_s": n / tot * 1e3,
-                      "mask_hbm_frac": (n * n / 16.0 + 20 * n) / (t_mask * 1e-3) / 1e9 / HBM_PEAK_GBPS}
-    r["note"] = "config 5 (replicas only); mask bytes = upper-triangular N^2/16 written; reduce is a serial chain"
+                      "mask_hbm_frac": (n * n / 16.0 + 20 * n) / (t_mask * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                      "mask_valu_frac": valu_frac("k_nms_mask", n, t_mask)}
+    r["note"] = ("config 5 (replicas only); mask bytes = upper-triangular N^2/16 written; k_nms_mask is VALU-bound (IoU test of "
+                 "N^2/2 pairs): mask_valu_frac = SQ_INSTS_VALU x 64 / time over the chip's 7.86e13 lane-ops/s; reduce is a serial chain; "
+                 "medians of 50 launches after 20 warm-up")
     return r
 
 
@@ -241,18 +345,40 @@ def extra_kmeans(d, n_total=10_000_000, iters=30):
     lo, hi = sh.shard_range(n_total, d.rank, d.world)
     per = hi - lo
     shard = torch.from_numpy(wh_all[lo:hi]).to(d.dev)
-    del wh_all
     km = cluster.kmean(5, 42, reduce_device="cpu" if d.rehearse else None)   # rehearsal: gloo reduces host tensors
-    km.fit(shard, init_centers=init, fixed_iters=iters)     # warm-up (RCCL channels, workspace); leaves the device state
-    sec = Dist.timed(d, lambda: km._run_iters(0, iters), 1, 0)   # the Lloyd iterations proper (step [+ all-reduce] + update)
+    km.fit(shard, init_centers=init, fixed_iters=iters)     # warm-up (RCCL channels, graph capture); leaves the device state
+    sec = min(Dist.timed(d, lambda: km._run_iters(0, iters), 1, 0) for _ in range(5))   # the Lloyd iterations proper
     # kernel-only rate of the step on this shard
     be = km._backend
-    ms = ev_time(be.step, 20, 3)
-    return {"iters_per_s": iters / sec, "ms_per_iter": sec / iters * 1e3, "boxes_total": n_total, "ranks": d.world,
-            "step_kernel_ms_per_shard": ms, "step_hbm_frac": (12.0 * per) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-            "centers": km.cluster_centers_.round(6).tolist(),
-            "note": "config 4, strong scaling: 10M boxes sharded, one 17 x int64 all-reduce per iteration; "
-                    "timed: 30 iterations of step [+ all-reduce] + centroid update, device-resident; on one rank the device-side loop forms the inertia sum in the last iteration only (a Lloyd iteration does not use it), the sharded loop in every step"}
+    ms = ev_median(be.step, 100, 20)
+    r = {"iters_per_s": iters / sec, "ms_per_iter": sec / iters * 1e3, "boxes_total": n_total, "ranks": d.world,
+         "sharded_loop": km.graph_state if d.world > 1 else "single device: dg_kmeans_iou_run",
+         "step_kernel_ms_per_shard": ms, "step_hbm_frac": (12.0 * per) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+         "step_valu_frac": valu_frac("k_kmeans_step", per, ms),
+         "centers": km.cluster_centers_.round(6).tolist(),
+         "note": "config 4, strong scaling: 10M boxes sharded; per iteration ONE launch (the centroid update is the prologue of "
+                 "the next step) + ONE 17 x int64 all-reduce, the 30 iterations replayed as one HIP graph when capture succeeds; "
+                 "timed: best of 5 runs of 30 iterations, device-resident; the inertia sum is formed by the last iteration of a "
+                 "run only, on one rank and on many alike; step_kernel = the plain step with the inertia, median of 100"}
+    if d.world == 1 and not d.rehearse:
+        # what the sharded loop costs per iteration on a 1/8 shard (1.25 M boxes), all-reduce included, on this one GPU:
+        # a single-rank RCCL group runs the same launch + all-reduce sequence the 8-GPU job runs on every rank
+        try:
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1, device_id=d.dev)
+            sub = torch.from_numpy(wh_all[:n_total // 8]).to(d.dev)
+            for mode in ("1", "0"):
+                os.environ["DG_KMEANS_GRAPH"] = mode
+                k8 = cluster.kmean(5, 42, sharded=True)
+                k8.fit(sub, init_centers=init, fixed_iters=iters)
+                s8 = min(Dist.timed(d, lambda: k8._run_iters(0, iters), 1, 0) for _ in range(5))
+                r["shard_1p25M_loop_graph" if mode == "1" else "shard_1p25M_loop_eager"] = {
+                    "us_per_iter": s8 / iters * 1e6, "state": k8.graph_state}
+            r["shard_1p25M_step_kernel_us"] = ev_median(k8._backend.step, 100, 20) * 1e3
+            os.environ.pop("DG_KMEANS_GRAPH", None)
+            dist.destroy_process_group()
+        except Exception as e:  # noqa: BLE001
+            r["shard_1p25M_loop_error"] = f"{type(e).__name__}: {e}"
+    return r
 
 
 T0 = time.perf_counter()
@@ -263,33 +389,75 @@ def trace(d, msg):
         print(f"[bench rank {d.rank} t={time.perf_counter() - T0:7.2f}s] {msg}", file=sys.stderr, flush=True)
 
 
+class StubBatch:
+    """DG_BENCH_STUB=1: a trivial CPU workload with the FrcnnBatch surface, so that the launcher, the process group, the
+    barriers / max-over-ranks timing and the reporting run where there is no GPU (tests/test_bench_launch.py).  It computes
+    nothing of the hot path and its line says so ("data": "stub")."""
+    n_rois = 2000
+
+    def __init__(self, d, images_total):
+        from vision_amd import shard
+        lo, hi = shard.shard_range(images_total, d.rank, d.world)
+        self.B, self.n = hi - lo, (hi - lo) * self.n_rois
+        self.x = np.arange(self.n, dtype=np.float64)
+
+    def step(self):
+        self.x = np.sqrt(self.x + 1.0)
+
+    def check(self):
+        assert np.isfinite(self.x).all()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--images", type=int, default=256, help="images in the global batch (config 3: 256)")
+    ap.add_argument("--images", type=int, default=256, help="images per batch (config 3: 256)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: every rank runs a full --images batch; strong: ONE --images batch split over the ranks")
     ap.add_argument("--no-extras", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     a = ap.parse_args()
-    d = Dist(a.gpus)
-    from vision_amd import _abi
-    _abi.load()
-
-    trace(d, "init done")
-    w = FrcnnBatch(d, a.images)
+    if a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a.gpus))            # no GPU call has been made in this process
+    stub = os.environ.get("DG_BENCH_STUB") == "1"
+    d = Dist(a.gpus, stub=stub)
+    images_total = a.images * d.world if a.scaling == "weak" else a.images
+    if stub:
+        w = StubBatch(d, images_total)
+    else:
+        from vision_amd import _abi
+        _abi.load()
+        trace(d, "init done")
+        w = FrcnnBatch(d, images_total)
     trace(d, "workload resident")
     sec = d.timed(w.step, a.steps, a.warmup)
     trace(d, "timed region done")
     w.check()
-    total_rois = a.images * w.n_rois
+    total_rois = images_total * w.n_rois
     ms_step = sec / a.steps * 1e3
     value = total_rois * a.steps / sec
+    line = {"metric": "RoIs/sec RoI-pool fwd+bwd + batched NMS (Fast R-CNN batch)", "value": value, "unit": "RoIs/s",
+            "n_gpus": d.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
+            "scaling": a.scaling, "vs_baseline": None, "dtype": "f32", "data": "stub" if stub else "synthetic",
+            "config": {"workload": f"configs[2]: Fast R-CNN batch {a.images} images x 2000 RoIs{' per GPU' if a.scaling == 'weak' else ''}, "
+                                   "512x38x50 maps, RoI max-pool 7x7 fwd(+argmax)+bwd + batched NMS thr 0.7, sharded by image",
+                       "images_per_gpu": w.B, "global_batch_images": images_total, "rois_per_image": 2000,
+                       "parallelism": f"image-shard x{d.world}, no data-path collective", "backend": d.backend,
+                       "world_size_seen": dist.get_world_size() if d.world > 1 else 1}}
+    if stub:
+        finish(d, line)
+        return
 
-    # dominant kernel, timed live with events on the launch stream (rank 0's shard)
-    t_fwd = ev_time(w.fwd, max(3, a.steps), 1)
-    phases = {"windows_ms": ev_time(w.windows, 3, 1), "nhwc_stage_ms": ev_time(w.stage, 3, 1), "roipool_fwd_ms": t_fwd,
-              "roipool_bwd_ms": ev_time(w.bwd, 3, 1), "nms_batched_ms": ev_time(w.nms, 3, 1)}
+    # dominant kernel and the other phases: 20 warm-up + median of 50 launches, HIP events on the launch stream (rank 0's shard)
+    reps = dict(iters=50, warm=20) if w.B >= 8 else dict(iters=100, warm=20)
+    t_fwd = ev_median(w.fwd, **reps)
+    phases = {"windows_ms": ev_median(w.windows, **reps), "nhwc_stage_ms": ev_median(w.stage, **reps), "roipool_fwd_ms": t_fwd,
+              "roipool_bwd_ms": ev_median(w.bwd, **reps), "nms_batched_ms": ev_median(w.nms, **reps),
+              "timing": f"median of {reps['iters']} launches after {reps['warm']} warm-up, one HIP event pair per launch"}
     fwd_bytes = w.n * ROI_BYTES + w.B * MAP_BYTES + w.n * 20
     achieved = fwd_bytes / (t_fwd * 1e-3) / 1e9
     traffic = None
@@ -310,7 +478,7 @@ def main():
         try:
             w.arg = torch.empty(tuple(w.out.shape), dtype=torch.int16, device=d.dev)
             sec16 = d.timed(w.step, a.steps, 1)
-            f16, b16 = ev_time(w.fwd, 3, 1), ev_time(w.bwd, 3, 1)
+            f16, b16 = ev_median(w.fwd, 20, 5), ev_median(w.bwd, 20, 5)
             a16 = {"value": total_rois * a.steps / sec16, "unit": "RoIs/s", "ms_per_step": sec16 / a.steps * 1e3,
                    "roipool_fwd_ms": f16, "roipool_bwd_ms": b16, "bytes_per_roi": ROI_BYTES_A16,
                    "fwd_hbm_frac": (w.n * ROI_BYTES_A16 + w.B * MAP_BYTES + w.n * 20) / (f16 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
@@ -321,17 +489,8 @@ def main():
             a16 = {"error": str(e)}
     del w
     torch.cuda.empty_cache()
-    # what a plain device-to-device copy reaches on this box (read + write bytes), as SURVEY 8(d) asks: the second yardstick
-    src = torch.empty(1 << 30, dtype=torch.float32, device=d.dev)
-    dst = torch.empty_like(src)
-    t_copy = ev_time(lambda: dst.copy_(src), 5, 2)
-    copy_gbps = 2 * src.numel() * 4 / (t_copy * 1e-3) / 1e9
-    del src, dst
-    torch.cuda.empty_cache()
-    roofline["d2d_copy_GBps"] = copy_gbps
-    roofline["frac_of_d2d_copy"] = achieved / copy_gbps
-
     extra = {"phases_ms_rank0": phases, "grad_out_aliases_out": gout_alias, "config3_uint16_argmax": a16}
+
     def side(name, fn):
         # a side configuration that fails is reported as such; it must not cost the primary line
         try:
@@ -340,10 +499,32 @@ def main():
             extra[name] = {"error": f"{type(e).__name__}: {e}"}
             print(f"[bench rank {d.rank}] {name} failed: {e!r}", file=sys.stderr, flush=True)
 
+    # ONE 256-image batch split over the ranks (BASELINE configs[2] as worded), next to the weak-scaling primary line
+    if d.world > 1 and a.scaling == "weak" and not a.no_extras:
+        def strong(d):
+            ws = FrcnnBatch(d, a.images)
+            sec_s = d.timed(ws.step, a.steps, a.warmup)
+            ws.check()
+            return {"value": a.images * ws.n_rois * a.steps / sec_s, "unit": "RoIs/s", "ms_per_step": sec_s / a.steps * 1e3,
+                    "images_per_gpu": ws.B, "global_batch_images": a.images, "scaling": "strong"}
+        side("config3_strong_scaling", strong)
+        torch.cuda.empty_cache()
+
+    # what a plain device-to-device copy reaches on this box (read + write bytes), as SURVEY 8(d) asks: the second yardstick
+    src = torch.empty(1 << 30, dtype=torch.float32, device=d.dev)
+    dst = torch.empty_like(src)
+    t_copy = ev_median(lambda: dst.copy_(src), 20, 5)
+    copy_gbps = 2 * src.numel() * 4 / (t_copy * 1e-3) / 1e9
+    del src, dst
+    torch.cuda.empty_cache()
+    roofline["d2d_copy_GBps"] = copy_gbps
+    roofline["frac_of_d2d_copy"] = achieved / copy_gbps
+
     if not a.no_extras:
         if d.rank == 0:
             side("config1_single_image", extra_single_image)
             side("config2_yolo1_b64", extra_yolo)
+            side("config3_wide_rois", extra_wide_rois)
             side("config5_stress_64k", extra_stress)
             torch.cuda.empty_cache()
         trace(d, "extras on rank 0 done / waiting")
@@ -353,15 +534,13 @@ def main():
     cpu = None
     if d.rank == 0 and d.world == 1 and not a.no_cpu:
         cpu = cpu_baseline_frcnn()
+    line.update({"roofline": roofline, "cpu_baseline": cpu, "extra": extra})
+    finish(d, line)
 
+
+def finish(d, line):
     if d.rank == 0:
-        line = {"metric": "RoIs/sec RoI-pool fwd+bwd + batched NMS (Fast R-CNN batch)", "value": value, "unit": "RoIs/s",
-                "n_gpus": d.world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_step, "higher_is_better": True,
-                "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": f"configs[2]: Fast R-CNN batch {a.images} images x 2000 RoIs, 512x38x50 maps, "
-                                       "RoI max-pool 7x7 fwd(+argmax)+bwd + batched NMS thr 0.7, sharded by image",
-                           "global_batch_images": a.images, "rois_per_image": 2000, "parallelism": f"image-shard x{d.world}"},
-                "roofline": roofline, "cpu_baseline": cpu, "extra": extra}
+        assert line["n_gpus"] == d.world
         print(json.dumps(line))
     sys.stdout.flush()
     if d.world > 1:

@@ -28,6 +28,15 @@ def frcnn_rois(seed, n=2000):
     return np.concatenate([xy, xy + wh], axis=1)
 
 
+def frcnn_rois_wide(seed, n=2000):
+    """Realistic proposal mix without a size bound (rcnn/fast_rcnn.py:366-369 puts none on the RoI): w,h ~ U(0.1,0.9) of
+    the map, i.e. crops of 4..46 x 4..35 cells on a 38x50 map; all non-empty."""
+    rng = np.random.default_rng(5000 + seed)
+    wh = rng.uniform(0.1, 0.9, (n, 2))
+    xy = rng.uniform(0.0, 1.0, (n, 2)) * (1.0 - wh)
+    return np.concatenate([xy, xy + wh], axis=1)
+
+
 def frcnn_feature_map(seed, b=1, c=512, h=38, w=50):
     rng = np.random.default_rng(1000 + seed)
     return rng.standard_normal((b, c, h, w), dtype=np.float32)
