@@ -140,3 +140,70 @@ def test_kmeans_10m_properties(va):
         sel = labels == c
         assert int(fx[sel, 0].sum()) == a[c] and int(fx[sel, 1].sum()) == a[5 + c] and int(sel.sum()) == a[10 + c]
     assert int(torch.round(dl.double() * 4294967296.0).long().sum()) == a[16]
+
+
+def test_config3_full_size_roipool_256_images(va):
+    """BASELINE configs[2] at its full size, 256 images x 2000 RoIs (512,000 RoIs; out + argmax + gradient = 154 GB, element
+    offsets pass 2^32): forward value = map[argmax] with the argmax inside its bin and equal to torch's own adaptive max
+    pool on sampled RoIs of every 16th image; backward equal to a torch scatter-add of the same (gradient, argmax) pairs
+    for EVERY image (fp32 sums in another order: 1e-4), i.e. also mass-conserving."""
+    from vision_amd import ops
+    images, n_rois = 256, 2000
+    dev = torch.device("cuda", 0)
+    torch.manual_seed(3)
+    img = torch.randn((images, 512, 38, 50), device=dev)
+    rois = torch.from_numpy(np.concatenate([wl.frcnn_rois(i, n_rois) for i in range(images)])).to(dev)
+    idx = torch.arange(images, device=dev).repeat_interleave(n_rois)
+    win, st = ops.roi_windows(rois, idx, images, 38, 50, dev)
+    assert int(st.item()) == 0
+    out, arg = ops.roipool_forward(img, win, "max")
+    n = win.shape[0]
+    assert n == images * n_rois and out.numel() > 2 ** 32
+    flat = img.view(images, 512, -1)
+    i7 = torch.arange(7, device=dev)
+    for b in range(images):
+        lo, hi = b * n_rois, (b + 1) * n_rois
+        a = arg[lo:hi].long().view(n_rois, 512, 49)
+        got = torch.gather(flat[b].unsqueeze(0).expand(n_rois, -1, -1), 2, a)
+        assert bool((got == out[lo:hi].view(n_rois, 512, 49)).all()), b
+        w_ = win[lo:hi].long()
+        assert bool((w_[:, 4] == b).all())
+        a = a.view(n_rois, 512, 7, 7)
+        ay, ax = a // 50, a % 50
+        Lh, Lw = (w_[:, 3] - w_[:, 1])[:, None], (w_[:, 2] - w_[:, 0])[:, None]
+        hs = w_[:, 1:2] + (i7[None] * Lh) // 7; he = w_[:, 1:2] + ((i7[None] + 1) * Lh + 6) // 7
+        ws = w_[:, 0:1] + (i7[None] * Lw) // 7; we = w_[:, 0:1] + ((i7[None] + 1) * Lw + 6) // 7
+        assert bool(((ay >= hs[:, None, :, None]) & (ay < he[:, None, :, None]) & (ax >= ws[:, None, None, :]) & (ax < we[:, None, None, :])).all()), b
+        if b % 16 == 15:
+            for r in (lo, lo + 777, hi - 1):
+                x1, y1, x2, y2, bb = [int(v) for v in win[r]]
+                ref, ri = torch.nn.functional.adaptive_max_pool2d(img[bb:bb + 1, :, y1:y2, x1:x2], 7, return_indices=True)
+                assert bool((ref[0] == out[r]).all())
+                # torch's index is relative to the crop
+                ry, rx = ri[0] // (x2 - x1) + y1, ri[0] % (x2 - x1) + x1
+                assert bool((ry * 50 + rx == arg[r].long()).all())
+    g = torch.randn_like(out)
+    gin = ops.roipool_backward(g, arg, win, img.shape, "max")
+    for b in range(images):
+        lo, hi = b * n_rois, (b + 1) * n_rois
+        want = torch.zeros((512, 38 * 50), device=dev, dtype=torch.float64)
+        want.scatter_add_(1, arg[lo:hi].long().view(n_rois, 512, 49).permute(1, 0, 2).reshape(512, -1),
+                          g[lo:hi].view(n_rois, 512, 49).permute(1, 0, 2).reshape(512, -1).double())
+        torch.testing.assert_close(gin[b].view(512, -1).double(), want, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("thr", [0.7, 0.3])
+def test_config3_full_size_batched_nms_256_images_vs_oracle(va, thr):
+    """BASELINE configs[2]: batched NMS over 256 images x 2000 proposals in one call, every image against the C oracle."""
+    from oracle import oracle as orc
+    from vision_amd import ops
+    orc.build()
+    images, n = 256, 2000
+    props = [wl.frcnn_proposals(i, n) for i in range(images)]
+    boxes = torch.from_numpy(np.stack([b for b, _ in props])).cuda()
+    scores = torch.from_numpy(np.stack([s for _, s in props])).cuda()
+    keep, cnt = ops.nms_batched(boxes, scores, None, thr, True)
+    keep, cnt = keep.cpu().numpy(), cnt.cpu().numpy()
+    for i, (b, s) in enumerate(props):
+        want = orc.nms(b, s, thr)
+        assert cnt[i] == len(want) and np.array_equal(keep[i, :cnt[i]], want), i
