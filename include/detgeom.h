@@ -73,6 +73,18 @@ int dg_nms_batched_f32(const float *boxes, const float *scores, const int32_t *c
 size_t dg_nms_noalloc_max_bytes(void);
 int dg_nms_batched_noalloc_f32(const float *boxes, const float *scores, const int32_t *counts, int64_t batch, int64_t nmax,
                                float threshold, int quirk_drop_last, int64_t *keep, int32_t *keep_count, dg_stream_t s);
+/* Per-class NMS (BASELINE.json configs[1] "per-class NMS").  NO COUNTERPART IN THE REFERENCE, whose nms is class-agnostic
+ * (yolo/yolo_v1/yolo.py:188-203; evaluate() splits the survivors by class afterwards, :282-298): this is that nms applied
+ * to each class's boxes of an image separately (quirk and tie rule as above, IoU bits unchanged -- no coordinate
+ * offsets).  labels: (batch,nmax) int64 in [0,num_classes), num_classes <= 256, batch*num_classes <= 65535.
+ * keep: (batch,nmax) int64 = the classes' keep lists (image indices, descending score inside a class) concatenated in
+ * class order; keep_count: (batch) totals; class_count: (batch,num_classes) int32 kept per class (may be NULL).
+ * *status (device int32, zeroed by the caller): bit 0 = a label outside [0,num_classes) was met (that box is ignored). */
+size_t dg_nms_per_class_workspace_bytes(int64_t batch, int64_t nmax, int64_t num_classes);
+int dg_nms_batched_per_class_f32(const float *boxes, const float *scores, const int64_t *labels, const int32_t *counts,
+                                 int64_t batch, int64_t nmax, int64_t num_classes, float threshold, int quirk_drop_last,
+                                 int64_t *keep, int32_t *keep_count, int32_t *class_count, int32_t *status, void *ws,
+                                 size_t ws_bytes, dg_stream_t s);
 /* phases of dg_nms_batched_f32, exposed for measurement (bench.py) and tests; same workspace */
 int dg_nms_phase_sort(const float *boxes, const float *scores, const int32_t *counts, int64_t batch, int64_t nmax,
                       void *ws, size_t ws_bytes, dg_stream_t s);

@@ -300,6 +300,65 @@ def test_decode_nms_config2_vs_oracle(va, oracle):
 
 
 # ------------------------------------------------------------------ RoI pool
+def _nms_per_class_oracle(oracle, boxes, scores, labels, C, thr, quirk):
+    """the spec of per-class mode: the oracle's (= the reference's) nms applied to each class's boxes in list order"""
+    keep, per = [], []
+    for c in range(C):
+        idx = np.flatnonzero(labels == c)
+        k = oracle.nms(boxes[idx], scores[idx], thr, quirk) if idx.size else np.zeros(0, np.int64)
+        keep.append(idx[k])
+        per.append(len(k))
+    return np.concatenate(keep) if keep else np.zeros(0, np.int64), per
+
+
+def test_decode_nms_config2_per_class_vs_oracle(va, oracle):
+    """BASELINE configs[1] as worded: YOLOv1 decode + PER-CLASS NMS, batch 64.  Parity unpinned vs the reference (its nms is
+    class-agnostic, yolo.py:282-298): checked against the oracle's nms applied per class.  Both box slots of a cell share the
+    class score, so this input has tied keys by construction: ties are "lower index first" on both sides."""
+    from vision_amd import yolo_v1
+    out, tgt = wl.yolo1_batch(0, 64)
+    box, label, conf, score, count, keep, kcnt, _, _ = yolo_v1.decode_nms_batched(torch.from_numpy(out).cuda(), torch.from_numpy(tgt).cuda(),
+                                                                                  0.2, 0.01, 0.3, per_class=True)
+    box, label, score, count, keep, kcnt = [t.cpu().numpy() for t in (box, label, score, count, keep, kcnt)]
+    assert count.max() > 60
+    for i in range(64):
+        m = count[i]
+        want, _ = _nms_per_class_oracle(oracle, box[i, :m], score[i, :m], label[i, :m], 5, 0.3, True)
+        assert kcnt[i] == len(want) and np.array_equal(keep[i, :kcnt[i]], want), i
+
+
+@pytest.mark.parametrize("quirk", [True, False])
+def test_nms_per_class_ragged_vs_oracle(va, oracle, quirk):
+    from vision_amd import ops
+    B, N, C = 5, 3000, 20
+    rng = np.random.default_rng(77)
+    props = [wl.frcnn_proposals(300 + i, N) for i in range(B)]
+    boxes = np.stack([b for b, _ in props]); scores = np.stack([s for _, s in props])
+    labels = rng.integers(0, C, (B, N)).astype(np.int64)
+    labels[1] = 7                                            # one class only
+    labels[2, :] = np.arange(N) % 3 + 17                     # classes 17..19 only
+    counts = np.array([N, N, 2999, 1, 0], np.int32)
+    keep, kcnt, ccnt, status = ops.nms_batched_per_class(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(),
+                                                         torch.from_numpy(labels).cuda(), C, torch.from_numpy(counts).cuda(), 0.5, quirk)
+    keep, kcnt, ccnt = keep.cpu().numpy(), kcnt.cpu().numpy(), ccnt.cpu().numpy()
+    assert int(status.item()) == 0
+    for i in range(B):
+        m = counts[i]
+        want, per = _nms_per_class_oracle(oracle, boxes[i, :m], scores[i, :m], labels[i, :m], C, 0.5, quirk)
+        assert kcnt[i] == len(want) and np.array_equal(keep[i, :kcnt[i]], want), i
+        assert list(ccnt[i]) == per
+    # a label outside [0, C) is reported and its box ignored
+    labels[0, 5] = C
+    labels[0, 6] = -1
+    keep2, kcnt2, _, status2 = ops.nms_batched_per_class(torch.from_numpy(boxes[:1]).cuda(), torch.from_numpy(scores[:1]).cuda(),
+                                                         torch.from_numpy(labels[:1]).cuda(), C, None, 0.5, quirk)
+    assert int(status2.item()) == 1
+    ok = np.ones(N, bool); ok[5] = ok[6] = False
+    idx = np.flatnonzero(ok)
+    want, _ = _nms_per_class_oracle(oracle, boxes[0][idx], scores[0][idx], labels[0][idx], C, 0.5, quirk)
+    assert np.array_equal(keep2.cpu().numpy()[0, :int(kcnt2[0])], idx[want])
+
+
 def test_roipool_golden(va, golden):
     from vision_amd import fast_rcnn
     g = golden("roipool")

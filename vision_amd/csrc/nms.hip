@@ -1026,3 +1026,162 @@ extern "C" int dg_nms_batched_noalloc_f32(const float *boxes, const float *score
     return dg_nms_batched_f32(boxes, scores, counts, batch, nmax, threshold, quirk_drop_last, keep, keep_count, ws,
                               (size_t)DG_NMS_NOALLOC_SCRATCH_BYTES, s);
 }
+
+// ---------------------------------------------------------------- per-class NMS (BASELINE.json configs[1])
+// NO COUNTERPART IN THE REFERENCE: its nms (yolo/yolo_v1/yolo.py:188-203) is class-agnostic and evaluate() splits the
+// survivors by class afterwards (:282-298).  Per-class mode = the reference's nms applied to each class's boxes of an
+// image separately (boxes of different classes never suppress each other), quirk and tie rule included.  It is built
+// from the batched NMS above without touching its kernels: every (image, class) pair becomes one ragged segment
+//   bin   : stable counting sort of an image's boxes by class into segment (image * C + class), remembering each
+//           box's index in the image (stable => ties keep "lower index first" inside a class);
+//   nms   : dg_nms_batched_f32 over batch * C segments with their counts (same IoU bits: no coordinate offsets);
+//   unbin : per image the classes' keep lists, mapped back to image indices, concatenated in class order.
+#define PC_MAX_CLASSES 256
+struct PcWs {
+    float *boxes, *scores;
+    int32_t *orig, *counts, *kcnt;
+    int64_t *keep;
+    void *nms_ws;
+    size_t nms_bytes, total;
+};
+static PcWs pc_layout(int64_t batch, int64_t nmax, int64_t C, void *base)
+{
+    PcWs w;
+    char *p = (char *)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *r = p + off; off += (bytes + 255) & ~(size_t)255; return r; };
+    const size_t seg = (size_t)batch * C;
+    w.boxes = (float *)take(seg * nmax * 16);
+    w.scores = (float *)take(seg * nmax * 4);
+    w.orig = (int32_t *)take(seg * nmax * 4);
+    w.counts = (int32_t *)take(seg * 4);
+    w.kcnt = (int32_t *)take(seg * 4);
+    w.keep = (int64_t *)take(seg * nmax * 8);
+    w.nms_bytes = dg_nms_workspace_bytes((int64_t)seg, nmax);
+    w.nms_ws = take(w.nms_bytes);
+    w.total = off;
+    return w;
+}
+
+// one workgroup per image; chunks of 1024 boxes in index order; rank inside the class = boxes of that class before
+// it (earlier chunks: s_base, earlier waves of this chunk: s_wave, earlier lanes: ballot)
+__global__ __launch_bounds__(1024) void k_nms_class_bin(const float4 *__restrict__ boxes, const float *__restrict__ scores,
+                                                        const int64_t *__restrict__ labels, const int32_t *__restrict__ counts,
+                                                        int64_t nmax, int C, float4 *__restrict__ sboxes, float *__restrict__ sscores,
+                                                        int32_t *__restrict__ sorig, int32_t *__restrict__ scounts,
+                                                        int32_t *__restrict__ status)
+{
+    __shared__ int s_base[PC_MAX_CLASSES];
+    __shared__ int s_wave[16][PC_MAX_CLASSES];
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = counts ? counts[img] : (int)nmax;
+    boxes += (int64_t)img * nmax;
+    scores += (int64_t)img * nmax;
+    labels += (int64_t)img * nmax;
+    for (int c = tid; c < C; c += 1024) s_base[c] = 0;
+    bool bad = false;
+    for (int c0 = 0; c0 < n; c0 += 1024) {
+        for (int t = tid; t < 16 * PC_MAX_CLASSES; t += 1024) (&s_wave[0][0])[t] = 0;
+        __syncthreads();
+        const int i = c0 + tid;
+        int cls = -1;
+        if (i < n) {
+            const int64_t l = labels[i];
+            if (l >= 0 && l < C) cls = (int)l;
+            else bad = true;
+        }
+        // lanes of one class: peel the classes present in the wave one by one (wave-uniform loop)
+        int rank = 0;
+        u64 todo = __ballot(cls >= 0);
+        while (todo) {
+            const int c = __builtin_amdgcn_readlane(cls, __builtin_amdgcn_readfirstlane(__builtin_ctzll(todo)));
+            const u64 m = __ballot(cls == c);
+            if (cls == c) {
+                rank = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+                if (rank == 0) s_wave[wave][c] = __builtin_popcountll(m);
+            }
+            todo &= ~m;
+        }
+        __syncthreads();
+        if (cls >= 0) {
+            int pos = s_base[cls] + rank;
+            for (int w = 0; w < wave; ++w) pos += s_wave[w][cls];
+            const int64_t o = ((int64_t)img * C + cls) * nmax + pos;
+            sboxes[o] = boxes[i];
+            sscores[o] = scores[i];
+            sorig[o] = i;
+        }
+        __syncthreads();
+        for (int c = tid; c < C; c += 1024) {
+            int s = 0;
+#pragma unroll
+            for (int w = 0; w < 16; ++w) s += s_wave[w][c];
+            s_base[c] += s;
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 1024) scounts[(int64_t)img * C + c] = s_base[c];
+    if (bad) atomicOr(status, 1);
+}
+
+__global__ __launch_bounds__(256) void k_nms_class_unbin(const int64_t *__restrict__ skeep, const int32_t *__restrict__ skcnt,
+                                                         const int32_t *__restrict__ sorig, int64_t nmax, int C,
+                                                         int64_t *__restrict__ keep, int32_t *__restrict__ keep_count,
+                                                         int32_t *__restrict__ class_count)
+{
+    __shared__ int s_off[PC_MAX_CLASSES + 1];
+    const int img = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        int o = 0;
+        for (int c = 0; c < C; ++c) { s_off[c] = o; o += skcnt[(int64_t)img * C + c]; }
+        s_off[C] = o;
+        keep_count[img] = o;
+    }
+    __syncthreads();
+    for (int c = 0; c < C; ++c) {
+        const int64_t seg = (int64_t)img * C + c;
+        const int k = s_off[c + 1] - s_off[c];
+        if (class_count && tid == 0) class_count[seg] = k;
+        for (int r = tid; r < k; r += 256) keep[(int64_t)img * nmax + s_off[c] + r] = (int64_t)sorig[seg * nmax + skeep[seg * nmax + r]];
+    }
+}
+
+extern "C" size_t dg_nms_per_class_workspace_bytes(int64_t batch, int64_t nmax, int64_t num_classes)
+{
+    if (batch <= 0 || nmax <= 0 || num_classes <= 0 || num_classes > PC_MAX_CLASSES) return 0;
+    return pc_layout(batch, nmax, num_classes, nullptr).total;
+}
+
+extern "C" int dg_nms_batched_per_class_f32(const float *boxes, const float *scores, const int64_t *labels, const int32_t *counts,
+                                            int64_t batch, int64_t nmax, int64_t num_classes, float threshold, int quirk_drop_last,
+                                            int64_t *keep, int32_t *keep_count, int32_t *class_count, int32_t *status, void *ws,
+                                            size_t ws_bytes, dg_stream_t s)
+{
+    DG_REQUIRE(batch >= 0 && nmax >= 0, "nms_per_class: negative size");
+    DG_REQUIRE(num_classes >= 1 && num_classes <= PC_MAX_CLASSES, "nms_per_class: num_classes must be in [1,%d]", PC_MAX_CLASSES);
+    DG_REQUIRE(batch * num_classes <= 65535, "nms_per_class: batch * num_classes > 65535");
+    DG_REQUIRE(keep_count && status, "nms_per_class: null keep_count / status");
+    hipStream_t st = (hipStream_t)s;
+    if (batch == 0) return DG_OK;
+    if (nmax == 0) {
+        if (hipMemsetAsync(keep_count, 0, (size_t)batch * 4, st) != hipSuccess) return DG_EHIP;
+        if (class_count && hipMemsetAsync(class_count, 0, (size_t)batch * num_classes * 4, st) != hipSuccess) return DG_EHIP;
+        return DG_OK;
+    }
+    DG_REQUIRE(boxes && scores && labels && keep, "nms_per_class: null pointer");
+    DG_REQUIRE((((uintptr_t)boxes) & 15) == 0, "nms_per_class: boxes must be 16-byte aligned");
+    DG_REQUIRE(ws && (((uintptr_t)ws) & 255) == 0, "nms_per_class: workspace null or not 256-byte aligned");
+    PcWs w = pc_layout(batch, nmax, num_classes, ws);
+    if (ws_bytes < w.total) { dg_set_error("nms_per_class: workspace %zu < %zu bytes", ws_bytes, w.total); return DG_ENOMEM; }
+    hipLaunchKernelGGL(k_nms_class_bin, dim3((unsigned)batch), dim3(1024), 0, st, (const float4 *)boxes, scores, labels, counts, nmax,
+                       (int)num_classes, (float4 *)w.boxes, w.scores, w.orig, w.counts, status);
+    DG_CHECK_LAUNCH("k_nms_class_bin");
+    int rc = dg_nms_batched_f32(w.boxes, w.scores, w.counts, batch * num_classes, nmax, threshold, quirk_drop_last, w.keep, w.kcnt,
+                                w.nms_ws, w.nms_bytes, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_nms_class_unbin, dim3((unsigned)batch), dim3(256), 0, st, w.keep, w.kcnt, w.orig, nmax, (int)num_classes, keep,
+                       keep_count, class_count);
+    DG_CHECK_LAUNCH("k_nms_class_unbin");
+    return DG_OK;
+}

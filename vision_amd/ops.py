@@ -74,6 +74,31 @@ def nms_batched(boxes, scores, counts=None, threshold=0.1, quirk_drop_last=True,
     return keep, keep_count
 
 
+def nms_batched_per_class(boxes, scores, labels, num_classes, counts=None, threshold=0.1, quirk_drop_last=True):
+    """Per-class NMS (no reference counterpart: its nms is class-agnostic, yolo.py:188-203): the reference's nms applied to
+    each class's boxes of an image separately.  labels (B,N) int64 in [0,num_classes).
+    -> keep (B,N) int64 (classes' keep lists concatenated in class order), keep_count (B), class_count (B,num_classes)."""
+    dev = _abi.device_of(boxes, scores)
+    boxes, scores = _f32c(boxes, dev), _f32c(scores, dev)
+    labels = _abi.to_dev(labels, torch.int64, dev)
+    B, N = scores.shape
+    if boxes.shape != (B, N, 4) or labels.shape != (B, N):
+        raise ValueError("nms_batched_per_class: boxes (B,N,4), scores (B,N), labels (B,N)")
+    if counts is not None:
+        counts = _abi.to_dev(counts, torch.int32, dev)
+    keep = torch.empty((B, N), dtype=torch.int64, device=dev)
+    keep_count = torch.empty((B,), dtype=torch.int32, device=dev)
+    class_count = torch.empty((B, int(num_classes)), dtype=torch.int32, device=dev)
+    status = torch.zeros((1,), dtype=torch.int32, device=dev)
+    nbytes = load().dg_nms_per_class_workspace_bytes(B, N, int(num_classes))
+    ws = workspace(dev, nbytes)
+    with torch.cuda.device(dev):
+        check(load().dg_nms_batched_per_class_f32(ptr(boxes), ptr(scores), ptr(labels), ptr(counts), B, N, int(num_classes),
+                                                  float(threshold), int(quirk_drop_last), ptr(keep), ptr(keep_count),
+                                                  ptr(class_count), ptr(status), ptr(ws), nbytes, stream_ptr(dev)))
+    return keep, keep_count, class_count, status
+
+
 # ------------------------------------------------------------------ YOLOv1 decode
 def yolo1_decode_batched(output, target=None, conf_threshold=0.2, prob_threshold=0.1):
     dev = _abi.device_of(output, target)
