@@ -215,7 +215,17 @@ def cpu_baseline_frcnn(images=12, n_rois=2000):
         usable = len(os.sched_getaffinity(0))
     except AttributeError:
         usable = os.cpu_count()
-    return {"value": images * n_rois / dt, "unit": "RoIs/s", "cores": 1, "kind": "port",
+    ref = None
+    try:    # the reference's own Python, timed in the build container by tools/time_reference_cpu.py (numbers only travel)
+        rj = json.load(open(os.path.join(ROOT, "profiles", "r02_reference_cpu.json")))
+        ms = {r["path"].split(",")[0]: r["median_ms"] for r in rj["rows"]}
+        step_ms = ms["max variant forward + autograd backward"] + [v for k, v in ms.items() if k.startswith("nms")][0]
+        ref = {"value": 2000 / step_ms * 1e3, "unit": "RoIs/s", "cores": rj["meta"]["torch_threads"],
+               "what": "reference functions (slowroipool with AdaptiveMaxPool2d fwd + autograd bwd, nms thr 0.7) on one config-1 image, "
+                       "build container, median of %d" % rj["meta"]["runs"]}
+    except Exception:  # noqa: BLE001
+        pass
+    return {"value": images * n_rois / dt, "unit": "RoIs/s", "cores": 1, "kind": "port", "reference_python_in_build_container": ref,
             "host": {"os_cpu_count": os.cpu_count(), "usable_cpus": usable, "torch_num_threads": torch.get_num_threads()},
             "sample": f"{images} images x {n_rois} RoIs of the same step (C oracle: RoI max-pool fwd+bwd + NMS 0.7), {dt:.1f} s, "
                       "single thread; the reference's own Python is timed in the build container only (BASELINE.md section 2, "

@@ -93,6 +93,12 @@ int dg_nms_phase_mask(const int32_t *counts, int64_t batch, int64_t nmax, float 
 int dg_nms_phase_reduce(const int32_t *counts, int64_t batch, int64_t nmax, int quirk_drop_last,
                         int64_t *keep, int32_t *keep_count, void *ws, size_t ws_bytes, dg_stream_t s);
 
+/* N2 nms(rects,scores): rcnn/fast_rcnn.py:590-610 -- no suppression there: the rects are ordered by
+ * np.argsort(scores)[::-1] (:601) and element 0 is returned (:610).  out_index (device int64) = index of the maximal
+ * score on the float64 scores as given; a NaN ranks above every number (argsort puts NaNs last), equal maxima resolve to
+ * the highest index.  n >= 1. */
+int dg_top_score_f64(const double *scores, int64_t n, int64_t *out_index, dg_stream_t s);
+
 /* ---------------------------------------------------------------- YOLOv1 decode
  * D1 decode(output,target,conf_threshold,prob_threshold): yolo/yolo_v1/yolo.py:115-186, batched.
  * output/target: (batch,7,7,10+C) fp32 (target may be NULL).  Per image: out_box (98,4) fp32,

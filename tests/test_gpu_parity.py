@@ -178,6 +178,62 @@ def test_nms_frcnn_top(va, golden):
     assert np.array_equal(r, t["best_rect"]) and s == float(t["best_score"])
 
 
+def test_nms_frcnn_top_ties_and_near_ties(va, oracle):
+    """fast_rcnn.py:601-610 takes the maximum on the scores as given (float64).  Near ties (distinct doubles that are one
+    fp32 value) must pick the true maximum; a NaN score ranks first, as argsort places NaNs last; among exactly equal
+    maxima the reference's pick is whatever numpy's unstable argsort does -- ours is the highest index."""
+    from vision_amd import fast_rcnn
+    rng = np.random.default_rng(5)
+    rects = [rng.integers(0, 200, 4) for _ in range(8)]
+    cases = {
+        "near": [0.6, 0.9000000001, 0.9000000002, 0.9, 0.1, 0.9000000001, 0.3, 0.2],
+        "tie": [0.6, 0.9, 0.2, 0.9, 0.1, 0.9, 0.3, 0.2],
+        "nan": [0.6, 0.9, float("nan"), 0.95, 0.1, 0.9, 0.3, 0.2],
+        "neg": [-3.0, -1.5, -1.5, -2.0, -9.0, -1.5000001, -7.0, -8.0],
+    }
+    for name, sc in cases.items():
+        r, s = fast_rcnn.nms(rects, sc)
+        wr, ws = oracle.nms_frcnn_top(rects, sc)
+        assert (s == ws) or (np.isnan(s) and np.isnan(ws)), name
+        if name in ("near", "nan"):
+            assert np.array_equal(r, wr), name
+        else:
+            # equal maxima: numpy's argsort is unstable (its order among equal keys differs between builds), so the
+            # reference's pick is implementation-defined; ours is the highest index
+            tied = [i for i, v in enumerate(sc) if v == max(sc)]
+            assert np.array_equal(r, rects[tied[-1]]), name
+            assert any(np.array_equal(wr, rects[i]) for i in tied), name
+    big = rng.random(100003)
+    big[[17, 5000, 99999]] = 2.0 + np.array([0.0, 1e-13, 0.0])
+    r, s = fast_rcnn.nms(np.arange(4 * 100003).reshape(-1, 4), big)
+    assert s == big[5000] and np.array_equal(r, np.arange(4 * 100003).reshape(-1, 4)[5000])
+    with pytest.raises(IndexError):
+        fast_rcnn.nms([], [])
+
+
+def test_nms_two_streams_do_not_share_scratch(va, oracle):
+    """ops.* take their scratch per (device, stream): two NMS calls in flight on two streams must both be right
+    (with one buffer per device they raced on masks and tickets)."""
+    from vision_amd import ops, _abi
+    n = 6000
+    sets = [wl.frcnn_proposals(40 + i, n) for i in range(2)]
+    want = [oracle.nms(b, s, 0.5) for b, s in sets]
+    dev = torch.device("cuda", 0)
+    tens = [(torch.from_numpy(b).to(dev)[None], torch.from_numpy(s).to(dev)[None]) for b, s in sets]
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    torch.cuda.synchronize()
+    for rep in range(10):
+        outs = []
+        for (b, s), st in zip(tens, streams):
+            with torch.cuda.stream(st):
+                outs.append(ops.nms_batched(b, s, None, 0.5, True))
+        torch.cuda.synchronize()
+        for (keep, cnt), w in zip(outs, want):
+            assert int(cnt[0]) == len(w) and np.array_equal(keep[0, :len(w)].cpu().numpy(), w), rep
+    keys = [k for k in _abi._ws if k[1] in (streams[0].cuda_stream, streams[1].cuda_stream)]
+    assert len(keys) == 2 and _abi._ws[keys[0]].data_ptr() != _abi._ws[keys[1]].data_ptr()
+
+
 # ------------------------------------------------------------------ decode / evaluate / ap
 def test_decode_golden(va, golden):
     from vision_amd import yolo_v1
@@ -457,6 +513,43 @@ def test_roipool_avg_every_crop_width(va, oracle):
         x1, y1, x2, y2 = wins[r]
         ref = torch.nn.functional.adaptive_avg_pool2d(x[idx[r]:idx[r] + 1, :, y1:y2, x1:x2], 7)[0]
         torch.testing.assert_close(out[r], ref, rtol=1e-6, atol=1e-6)
+
+
+def _every_width_rois(H, W, rng, per_width=2):
+    """normalised RoIs whose crops take every width 1..W and many heights on an HxW map"""
+    rois = []
+    for w in range(1, W + 1):
+        for _ in range(per_width):
+            h = int(rng.integers(1, H + 1))
+            x1 = int(rng.integers(0, W - w + 1)); y1 = int(rng.integers(0, H - h + 1))
+            rois.append([(x1 + 0.3) / W, (y1 + 0.3) / H, (x1 + w - 0.3) / W, (y1 + h - 0.3) / H])
+    return np.array(rois, np.float64)
+
+
+@pytest.mark.parametrize("B,C,H,W,reps", [(2, 70, 38, 50, 2), (2, 128, 38, 50, 2), (1, 6, 70, 90, 2), (1, 8, 38, 50, 45), (3, 4, 20, 100, 3)])
+def test_roipool_avg_backward_vs_oracle(va, oracle, B, C, H, W, reps):
+    """avg-mode backward (the reference class as written + autograd) against the oracle on every crop width: channel counts
+    that leave a partial slice (C % 4 != 0: the planar cb < 4 path), maps wider and taller than 64 cells (the row-segment
+    walk and the integer-division bin ranges), and one image with >= 2048 RoIs (the RoI list is split over gridDim.z and the
+    slices are added with global atomics)."""
+    from vision_amd import ops
+    rng = np.random.default_rng(B * 1000 + C)
+    rois = np.concatenate([_every_width_rois(H, W, rng) for _ in range(reps)])
+    n = rois.shape[0]
+    idx = rng.integers(0, B, n).astype(np.int64)
+    img_shape = (B, C, H, W)
+    gout = rng.standard_normal((n, C, 7, 7)).astype(np.float32)
+    dev = torch.device("cuda", 0)
+    win, st = ops.roi_windows(rois, idx, B, H, W, dev)
+    assert int(st.item()) == 0
+    got = ops.roipool_backward(torch.from_numpy(gout).to(dev), None, win, img_shape, "avg").cpu().numpy()
+    want = oracle.roipool_bwd(gout, None, img_shape, rois, idx, 7, "avg")
+    np.testing.assert_allclose(got, want, rtol=1e-4, atol=1e-4)
+    # and the forward of the same set (values only: avg has no argmax)
+    img = rng.standard_normal(img_shape).astype(np.float32)
+    out, _ = ops.roipool_forward(torch.from_numpy(img).to(dev), win, "avg")
+    wout, _ = oracle.roipool_fwd(img, rois, idx, 7, "avg")
+    np.testing.assert_allclose(out.cpu().numpy(), wout, rtol=1e-5, atol=1e-5)
 
 
 def test_roipool_odd_channels_and_batch(va, oracle):

@@ -1185,3 +1185,43 @@ extern "C" int dg_nms_batched_per_class_f32(const float *boxes, const float *sco
     DG_CHECK_LAUNCH("k_nms_class_unbin");
     return DG_OK;
 }
+
+// ---------------------------------------------------------------- N2: rcnn/fast_rcnn.py:590-610
+// The reference's function called `nms` there suppresses nothing: it orders the rects by np.argsort(scores)[::-1]
+// and returns element 0, i.e. the rect of the maximal score on the ORIGINAL float64 scores.  One workgroup: the index
+// of the maximum, a NaN ranking above every number (argsort puts NaNs last) and, among equal maxima, the highest index
+// (what reversing an ascending order yields when equal keys stay in index order).
+__global__ __launch_bounds__(1024) void k_top_score_f64(const double *__restrict__ scores, int64_t n, int64_t *__restrict__ out)
+{
+    __shared__ double sv[1024];
+    __shared__ long long si[1024];
+    const int tid = threadIdx.x;
+    double bv = 0.0;
+    long long bi = -1;
+    auto better = [](double v, long long i, double bv, long long bi) {        // (v,i) outranks (bv,bi)
+        if (bi < 0) return true;
+        const bool vn = v != v, bn = bv != bv;
+        if (vn != bn) return vn;
+        if (!vn && v != bv) return v > bv;
+        return i > bi;
+    };
+    for (int64_t i = tid; i < n; i += 1024) {
+        const double v = scores[i];
+        if (better(v, i, bv, bi)) { bv = v; bi = i; }
+    }
+    sv[tid] = bv; si[tid] = bi;
+    __syncthreads();
+    for (int d = 512; d > 0; d >>= 1) {
+        if (tid < d && si[tid + d] >= 0 && better(sv[tid + d], si[tid + d], sv[tid], si[tid])) { sv[tid] = sv[tid + d]; si[tid] = si[tid + d]; }
+        __syncthreads();
+    }
+    if (tid == 0) *out = si[0];
+}
+
+extern "C" int dg_top_score_f64(const double *scores, int64_t n, int64_t *out_index, dg_stream_t s)
+{
+    DG_REQUIRE(n >= 1 && scores && out_index, "top_score: need n >= 1 and non-null pointers");
+    hipLaunchKernelGGL(k_top_score_f64, dim3(1), dim3(1024), 0, (hipStream_t)s, scores, n, out_index);
+    DG_CHECK_LAUNCH("k_top_score_f64");
+    return DG_OK;
+}

@@ -4,9 +4,10 @@
   nms(rects, scores) -> (rect, score)                      rcnn/fast_rcnn.py:590-610
 
 As written the reference pools with AdaptiveAvgPool2d stored in a field called `maxpool`
-(:354) and never defines backward (autograd).  `mode="max"` (default, what north_star asks
-for) is the same module with AdaptiveMaxPool2d substituted and also yields the argmax used by
-the backward scatter; `mode="avg"` is the literal reference.
+(:354) and never defines backward (autograd).  `mode="avg"` (the default: an import swap must
+reproduce the class as written) is that; `mode="max"` is the RoI MAX-pooling north_star asks
+for -- the same module with AdaptiveMaxPool2d substituted -- and also yields the argmax used
+by the backward scatter.
 """
 import numpy as np
 import torch
@@ -31,7 +32,7 @@ class _RoIPoolFn(torch.autograd.Function):
 
 
 class slowroipool(torch.nn.Module):
-    def __init__(self, output_size, mode="max"):
+    def __init__(self, output_size, mode="avg"):
         super().__init__()
         size = tuple(output_size) if isinstance(output_size, (tuple, list)) else (output_size, output_size)
         if size != (7, 7):
@@ -65,12 +66,19 @@ class slowroipool(torch.nn.Module):
 
 
 def nms(rects, scores):
-    """The reference's function of this name does no suppression and returns the top-score rect
-    (:601-610); a greedy NMS's first keep is that same rect, so the GPU path is output-compatible."""
+    """rcnn/fast_rcnn.py:590-610.  The reference's function of this name does no suppression: it orders the rects by
+    np.argsort(scores)[::-1] and returns element 0 -- the rect of the maximal score, taken on the scores as given
+    (float64).  That is what runs here (dg_top_score_f64): exact on scores that differ below fp32 resolution; equal
+    maxima resolve to the highest index (in the reference the order among equal keys is whatever numpy's unstable
+    argsort produces, so its pick among exactly tied scores is implementation-defined)."""
     rects_a = np.array(rects)
     scores_a = np.array(scores)
-    boxes = torch.as_tensor(rects_a.astype(np.float32)).reshape(1, -1, 4)
-    sc = torch.as_tensor(scores_a.astype(np.float32)).reshape(1, -1)
-    keep, cnt = ops.nms_batched(boxes, sc, None, 0.7, quirk_drop_last=False)
-    top = int(keep[0, 0].item())
+    if scores_a.size == 0:
+        raise IndexError("index 0 is out of bounds for axis 0 with size 0")     # what nms_rects[0] raises in the reference
+    dev = ops._abi.device_of(None)
+    sc = ops._abi.to_dev(scores_a.astype(np.float64).reshape(-1), torch.float64, dev)
+    top = torch.empty((1,), dtype=torch.int64, device=dev)
+    with torch.cuda.device(dev):
+        ops.check(ops.load().dg_top_score_f64(ops.ptr(sc), sc.shape[0], ops.ptr(top), ops.stream_ptr(dev)))
+    top = int(top.item())
     return rects_a[top], scores_a[top]

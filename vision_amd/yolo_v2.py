@@ -12,7 +12,10 @@ from ._abi import check, load, ptr, stream_ptr
 from .yolo_v1 import get_iou, _back  # noqa: F401  (same function in the reference)
 
 
-def get_point(output_size=56, bbox=None):
+def get_point(output_size=56, bbox=[0.1, 0.2, 0.3, 0.4]):  # noqa: B006  (the reference's signature, utils.py:228)
+    if isinstance(bbox, (list, tuple)):
+        # the reference evaluates bbox[2:]/2 (:229): a plain list -- its own default included -- raises there
+        raise TypeError("unsupported operand type(s) for /: 'list' and 'int'")
     single = torch.as_tensor(bbox).dim() == 1
     dev = _abi.device_of(bbox)
     b = _abi.to_dev(bbox, torch.float32, dev).reshape(-1, 4)
