@@ -1,5 +1,5 @@
 """Profiling driver: runs one hot-path phase a few times (used under rocprofv3).
-usage: python3 tools/prof_roi.py {fwd|bwd|kmeans|nms64k|pairwise} [images] [a32]   (RoI pooling: uint16 argmax unless a32)"""
+usage: python3 tools/prof_roi.py {fwd|bwd|fwdwide|kmeans|kmeans_shard|nms64k|nms256|pairwise} [images] [a32]   (RoI pooling: uint16 argmax unless a32)"""
 import os
 import sys
 
@@ -14,21 +14,22 @@ from tools import workloads as wl  # noqa: E402
 what = sys.argv[1] if len(sys.argv) > 1 else "fwd"
 images = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 dev = torch.device("cuda", 0)
-if what in ("fwd", "bwd"):
+if what in ("fwd", "bwd", "fwdwide"):
     img = torch.randn((images, 512, 38, 50), device=dev)
-    rois = torch.from_numpy(np.concatenate([wl.frcnn_rois(i) for i in range(images)])).to(dev)
+    gen = wl.frcnn_rois_wide if what == "fwdwide" else wl.frcnn_rois
+    rois = torch.from_numpy(np.concatenate([gen(i) for i in range(images)])).to(dev)
     idx = torch.arange(images, device=dev).repeat_interleave(2000)
     win, st = ops.roi_windows(rois, idx, images, 38, 50, dev)
     nhwc, nanf = ops.to_nhwc(img)
     adt = torch.int32 if (len(sys.argv) > 3 and sys.argv[3] == "a32") else torch.int16
     out, arg = ops.roipool_forward(img, win, "max", nhwc=nhwc, nan_flag=nanf, argmax_dtype=adt)
     for _ in range(3):
-        if what == "fwd":
+        if what in ("fwd", "fwdwide"):
             ops.roipool_forward(img, win, "max", out=out, argmax=arg, nhwc=nhwc, nan_flag=nanf)
         else:
             ops.roipool_backward(out, arg, win, img.shape, "max")
-elif what == "kmeans":
-    wh = torch.from_numpy(wl.anchor_wh(0, 10_000_000)).to(dev)
+elif what in ("kmeans", "kmeans_shard"):
+    wh = torch.from_numpy(wl.anchor_wh(0, 10_000_000 if what == "kmeans" else 1_250_000)).to(dev)
     cent = wh[:5].clone()
     labels = torch.zeros(wh.shape[0], dtype=torch.uint8, device=dev)
     acc = torch.zeros(17, dtype=torch.int64, device=dev)
@@ -38,8 +39,14 @@ elif what == "nms64k":
     b, s = wl.stress_boxes(0, 65536, dense=False)
     for _ in range(2):
         ops.nms_batched(torch.from_numpy(b).to(dev).reshape(1, -1, 4), torch.from_numpy(s).to(dev).reshape(1, -1), None, 0.5, True)
+elif what == "nms256":
+    props = [wl.frcnn_proposals(i, 2000) for i in range(256)]
+    bb = torch.from_numpy(np.stack([b for b, _ in props])).to(dev)
+    ss = torch.from_numpy(np.stack([s for _, s in props])).to(dev)
+    for _ in range(3):
+        ops.nms_batched(bb, ss, None, 0.7, True)
 elif what == "pairwise":
-    b, s = wl.stress_boxes(0, 32768, dense=False)
+    b, s = wl.stress_boxes(0, 65536, dense=False)
     bt = torch.from_numpy(b).to(dev)
     for _ in range(3):
         ops.iou_pairwise(bt, bt)
