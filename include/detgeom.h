@@ -158,31 +158,37 @@ int dg_roipool_bwd_a16_f32(const float *grad_out, const uint16_t *argmax16, cons
 /* ---------------------------------------------------------------- anchor k-means (1-IoU)
  * K1: the reference only fixes the sklearn-style API (clustering/cluster_prac.py:38-40); the 1-IoU
  * Lloyd step is build-defined (spec: oracle/oracle.c orc_kmeans_step / SURVEY.md §8(a) K1).
- * wh (n,2) fp32; cent (k,2) fp32; labels (n) uint8 in/out; acc (3k+2) int64 =
- * {sum_w[k], sum_h[k], count[k], changed, inertia_fx} is OVERWRITTEN with this shard's sums
- * (all-reduce it across ranks, then call dg_kmeans_update).  k <= 16.  wh 8-byte and ws 16-byte aligned;
- * |w|, |h| < 2^31 (the fixed-point sums hold x * 2^32 in int64).  One launch: the workgroup that finishes
- * last folds the per-workgroup rows held in ws.  Calls that share a workspace must be stream-ordered. */
+ * wh (n,2) fp32, 8-byte aligned; cent (k,2) fp32; labels (n) uint8 in/out; k <= 16; |w|, |h| < 2^31 (the fixed-point
+ * sums hold x * 2^32 in int64).  acc (3k+2) int64 = {sum_w[k], sum_h[k], count[k], changed, inertia_fx}.
+ *
+ * dg_kmeans_iou_step: one step with the centroids as given; acc is OVERWRITTEN with this shard's sums.  ws 16-byte
+ * aligned, dg_kmeans_workspace_bytes(n,k) bytes; calls that share a workspace must be stream-ordered. */
 size_t dg_kmeans_workspace_bytes(int64_t n, int64_t k);
 int dg_kmeans_iou_step(const float *wh, int64_t n, const float *cent, int64_t k, uint8_t *labels, int64_t *acc,
                        void *ws, size_t ws_bytes, dg_stream_t s);
-/* One iteration of the SHARDED Lloyd loop as ONE launch: the centroid update is the prologue of the next step, so an
- * iteration costs one launch + one all-reduce of acc.  apply_prev != 0: acc holds the ALL-REDUCED sums of the previous
- * iteration; every workgroup first moves the centroids by them (as dg_kmeans_update would), the new centroids are
- * written back to cent and history[slot] (may be NULL) receives the previous iteration's changed count; then the step
- * runs and acc is OVERWRITTEN with this shard's sums.  apply_prev == 0: a plain step (first iteration of a sequence).
- * want_inertia == 0 leaves acc[3k+1] = 0.  After the last iteration call dg_kmeans_update on the all-reduced acc.
- * A call with apply_prev != 0 must follow a dg_kmeans_iou_iter call on the same workspace, stream-ordered, with no
- * other user of that workspace in between. */
-int dg_kmeans_iou_iter(const float *wh, int64_t n, float *cent, int64_t k, uint8_t *labels, int64_t *acc,
-                       int apply_prev, int want_inertia, int64_t *history, int64_t slot, void *ws, size_t ws_bytes,
+/* The SHARDED Lloyd loop: one launch + one all-reduce per iteration, nothing else.  A launch adds its workgroups' rows
+ * into a "partial sums" buffer `part` of dg_kmeans_part_elems(k) int64 (8 replica rows of {the acc columns, padding}:
+ * workgroups sharing an XCD share a row) with 64-bit global atomics -- no workgroup waits for another.  The buffer is
+ * folded, and the centroids moved, by the PROLOGUE of the next launch, after the caller has all-reduced the whole buffer
+ * across ranks (integer sums: any rank count gives the same bits).
+ *   part_prev: the previous iteration's buffer (all-reduced), or NULL for the first iteration (centroids as given);
+ *              with it, cent is first moved (empty cluster keeps its centroid), written back, and history[slot]
+ *              (may be NULL) receives the previous iteration's changed count;
+ *   part_out:  this launch adds into it; it must arrive ZEROED;
+ *   part_zero: a third buffer this launch zeroes for the next launch to add into (NULL: none).
+ * Rotate three buffers: launch t uses (prev, out, zero) = (t-1, t, t+1) mod 3.  want_inertia == 0 leaves the inertia
+ * column 0 (a Lloyd iteration does not use it).  After the last iteration all-reduce its buffer and call
+ * dg_kmeans_finish: acc_out[3k+2] (may be NULL) = the folded sums, cent (may be NULL) moved by them,
+ * history[slot] (may be NULL) = changed count. */
+size_t dg_kmeans_part_elems(int64_t k);
+int dg_kmeans_iou_iter(const float *wh, int64_t n, float *cent, int64_t k, uint8_t *labels, const int64_t *part_prev,
+                       int64_t *part_out, int64_t *part_zero, int want_inertia, int64_t *history, int64_t slot,
                        dg_stream_t s);
-/* centroid = sum/count (int64 fixed point 2^32 -> fp32); empty cluster keeps its centroid.
- * history (may be NULL): history[slot] = acc[3k] (changed count of this iteration). */
-int dg_kmeans_update(const int64_t *acc, int64_t k, float *cent, int64_t *history, int64_t slot, dg_stream_t s);
-/* `iters` iterations of step+update back to back on ONE device (no all-reduce), one launch per iteration:
- * history[slot0+t] = changed count.  acc is left as the LAST iteration wrote it; only that iteration forms the
- * inertia sum acc[3k+1] (a Lloyd iteration does not need it), the earlier ones write 0 there. */
+int dg_kmeans_finish(const int64_t *part, int64_t k, float *cent, int64_t *acc_out, int64_t *history, int64_t slot,
+                     dg_stream_t s);
+/* `iters` iterations back to back on ONE device (no all-reduce), one launch per iteration (+ one memset before and the
+ * finish after): history[slot0+t] = changed count of iteration t; acc = the sums of the LAST iteration, the only one
+ * that forms the inertia sum acc[3k+1]. */
 int dg_kmeans_iou_run(const float *wh, int64_t n, float *cent, int64_t k, uint8_t *labels, int64_t *acc,
                       int64_t *history, int64_t slot0, int64_t iters, void *ws, size_t ws_bytes, dg_stream_t s);
 int dg_kmeans_labels_i32(const uint8_t *labels, int64_t n, int32_t *out, dg_stream_t s);

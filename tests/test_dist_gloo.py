@@ -52,6 +52,12 @@ class OracleBackend:
         self.cent = self.orc.kmeans_update(a, self.cent)
         self.history[slot] = a[3 * self.k]
 
+    def begin(self):
+        pass
+
+    def reduce_buffer(self):
+        return self.acc
+
     def iterate(self, apply_prev, inertia, slot):
         if apply_prev:
             self.update(slot)

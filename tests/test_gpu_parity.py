@@ -747,12 +747,14 @@ def test_kmeans_sharded_iter_two_shards_vs_oracle(va, oracle):
         be = cluster._HipBackend()
         be.prepare(x[lo:hi], init, k, iters)
         shards.append(be)
+    for be in shards:
+        be.begin()
     for t in range(iters):
         for be in shards:
             be.iterate(t > 0, t + 1 == iters, t - 1)
-        total = shards[0].acc + shards[1].acc
+        total = shards[0].reduce_buffer() + shards[1].reduce_buffer()       # what the all-reduce does
         for be in shards:
-            be.acc.copy_(total)
+            be.reduce_buffer().copy_(total)
     for be in shards:
         be.update(iters - 1)
     cent, labels, n_iter, inertia = oracle.kmeans_fit(wh, k, 42, fixed_iters=iters)

@@ -49,8 +49,9 @@ SIGNATURES = {
     "dg_roipool_bwd_a16_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, C.c_int, _vp, _vp, _sz, _vp]),
     "dg_kmeans_workspace_bytes": (_sz, [_i64, _i64]),
     "dg_kmeans_iou_step": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _sz, _vp]),
-    "dg_kmeans_iou_iter": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, C.c_int, C.c_int, _vp, _i64, _vp, _sz, _vp]),
-    "dg_kmeans_update": (C.c_int, [_vp, _i64, _vp, _vp, _i64, _vp]),
+    "dg_kmeans_part_elems": (_sz, [_i64]),
+    "dg_kmeans_iou_iter": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _vp, C.c_int, _vp, _i64, _vp]),
+    "dg_kmeans_finish": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "dg_kmeans_iou_run": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _sz, _vp]),
     "dg_kmeans_labels_i32": (C.c_int, [_vp, _i64, _vp, _vp]),
     "dg_rcnn_calcul_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),

@@ -24,14 +24,18 @@ class _HipBackend:
 
     def prepare(self, X, init_centers, k, iters):
         dev = _abi.device_of(X)
+        lib = _abi.load()
         self.wh = _abi.to_dev(X, torch.float32, dev).reshape(-1, 2)
         self.cent = _abi.to_dev(np.asarray(init_centers, np.float32), torch.float32, dev).reshape(k, 2).clone()
         self.labels = torch.full((self.wh.shape[0],), 255, dtype=torch.uint8, device=dev)
         self.acc = torch.zeros(3 * k + 2, dtype=torch.int64, device=dev)
         self.history = torch.zeros(max(iters, 1), dtype=torch.int64, device=dev)
-        # the launch ticket lives in the workspace across the calls of a chunk: this loop owns its workspace
-        self.ws_bytes = _abi.load().dg_kmeans_workspace_bytes(self.wh.shape[0], k)
+        # single device: workspace of dg_kmeans_iou_run; sharded: three partial-sums buffers in rotation (include/detgeom.h),
+        # `part[i]` is what gets all-reduced
+        self.ws_bytes = lib.dg_kmeans_workspace_bytes(self.wh.shape[0], k)
         self.ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=dev)
+        self.part = torch.zeros((3, lib.dg_kmeans_part_elems(k)), dtype=torch.int64, device=dev)
+        self.cur = None               # index of the buffer the last launch added into
         self._bound = None
 
     def run_local(self, slot0, iters):
@@ -49,15 +53,15 @@ class _HipBackend:
         dev = self.wh.device
         n, k = self.wh.shape[0], self.cent.shape[0]
         st = _abi.stream_ptr(dev)
-        head = (_abi.ptr(self.wh), n, _abi.ptr(self.cent), k, _abi.ptr(self.labels), _abi.ptr(self.acc))
-        tail = (_abi.ptr(self.ws), self.ws_bytes, st)
+        head = (_abi.ptr(self.wh), n, _abi.ptr(self.cent), k, _abi.ptr(self.labels))
         hist = _abi.ptr(self.history)
-        u = (_abi.ptr(self.acc), k, _abi.ptr(self.cent), hist)
-        step_fn, iter_fn, upd_fn, check = lib.dg_kmeans_iou_step, lib.dg_kmeans_iou_iter, lib.dg_kmeans_update, _abi.check
+        parts = [_abi.ptr(self.part[i]) for i in range(3)]
+        iter_fn, fin_fn, check = lib.dg_kmeans_iou_iter, lib.dg_kmeans_finish, _abi.check
+        cent, acc = _abi.ptr(self.cent), _abi.ptr(self.acc)
         self._bound = (dev, st.value,
-                       lambda: check(step_fn(*head, *tail)),
-                       lambda slot: check(upd_fn(*u, slot, st)),
-                       lambda apply_prev, inertia, slot: check(iter_fn(*head, apply_prev, inertia, hist, slot, *tail)))
+                       lambda prev, out, zero, inertia, slot: check(iter_fn(*head, parts[prev] if prev is not None else None,
+                                                                            parts[out], parts[zero], inertia, hist, slot, st)),
+                       lambda cur, slot: check(fin_fn(parts[cur], k, cent, acc, hist, slot, st)))
 
     def _fast(self):
         b = getattr(self, "_bound", None)
@@ -66,20 +70,32 @@ class _HipBackend:
             b = self._bound
         return b
 
-    def step(self):
-        """plain step: acc <- this shard's sums (with the inertia), centroids untouched"""
-        with torch.cuda.device(self.wh.device):
-            self._fast()[2]()
-
-    def update(self, slot):
-        with torch.cuda.device(self.wh.device):
-            self._fast()[3](slot)
+    def begin(self):
+        """start of a chunk of sharded iterations: all three buffers zero, no previous sums"""
+        self.part.zero_()
+        self.cur = None
 
     def iterate(self, apply_prev, inertia, slot):
-        """one sharded iteration as one launch: [centroids <- previous all-reduced acc; history[slot] <- its changed
-        count;] step; acc <- this shard's sums"""
+        """one sharded iteration as one launch: [centroids <- the previous (all-reduced) buffer; history[slot] <- its changed
+        count;] step; this shard's sums are ADDED into the next buffer of the rotation (`reduce_buffer()`)"""
+        prev = self.cur if apply_prev else None
+        out = 0 if self.cur is None else (self.cur + 1) % 3
         with torch.cuda.device(self.wh.device):
-            self._fast()[4](int(apply_prev), int(inertia), slot)
+            self._fast()[2](prev, out, (out + 1) % 3, int(inertia), slot)
+        self.cur = out
+
+    def reduce_buffer(self):
+        """the tensor to all-reduce (SUM) across ranks after iterate()"""
+        return self.part[self.cur]
+
+    def update(self, slot):
+        """after the last iteration of a chunk (and its all-reduce): fold, move the centroids, history[slot] <- changed"""
+        with torch.cuda.device(self.wh.device):
+            self._fast()[3](self.cur, slot)
+
+    def step(self):
+        """plain step (kernel + fold): acc <- this shard's sums with the inertia, centroids untouched"""
+        ops.kmeans_step(self.wh, self.cent, self.labels, self.acc)
 
     def history_host(self, upto):
         return self.history[:upto].cpu().numpy()
@@ -164,12 +180,13 @@ class kmean:
         return self
 
     def _sharded_chunk(self, slot0, count):
-        """count iterations: [launch, all-reduce] x count, then the last update.  The inertia is formed by the
+        """count iterations: [launch, all-reduce] x count, then the finish.  The inertia is formed by the
         chunk's last launch only, exactly as dg_kmeans_iou_run does on a single device."""
         be = self._backend
+        be.begin()
         for j in range(count):
             be.iterate(j > 0, j + 1 == count, slot0 + j - 1)
-            self._allreduce(be.acc)
+            self._allreduce(be.reduce_buffer())
         be.update(slot0 + count - 1)
 
     def _run_iters(self, slot0, count):

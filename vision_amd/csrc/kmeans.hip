@@ -3,10 +3,14 @@
 // is build-defined and specified in oracle/oracle.c (orc_kmeans_step / orc_kmeans_update):
 //   d = 1 - inter/((w*h + cw*ch) - inter), fp32, ties -> lowest index; sums in int64 fixed point
 //   (llrint(x * 2^32)) so any sharding / reduction order gives identical bits.
-// Step kernel: grid-stride, two boxes per lane per 16-byte load, centroids in SGPRs, per-lane
-// partial sums in LDS -> wave shuffle reduce -> one partial row per workgroup (plain stores); the workgroup
-// that finishes last folds the rows into acc[3k+2] and, in the device-side loop, updates the centroids.
+// Step kernel: grid-stride, two boxes per lane per 16-byte load, centroids in SGPRs, per-lane partial sums in LDS ->
+// wave shuffle reduce -> one row per workgroup, added with 64-bit global atomics into one of KM_REPL replica rows of a
+// "partial sums" buffer (replica = blockIdx % 8: workgroups that share an XCD share a row).  Nothing in a launch waits
+// for another workgroup: the replicas are folded, and the centroids moved, by the PROLOGUE of the next launch (every
+// workgroup does it for itself: 8 x (3k+2) int64), or by k_kmeans_finish after the last one.  A Lloyd iteration is one
+// launch (+ one all-reduce of the replica buffer when the boxes are sharded over GPUs).
 #include "common.hpp"
+#include <stdlib.h>
 
 #define KM_BLOCK 256
 #define KM_MAXBLOCKS 1024
@@ -100,13 +104,13 @@ __device__ __forceinline__ unsigned long long fx32_biased(float v)
 
 template <bool FAST, bool INERTIA = true>
 __device__ __forceinline__ void km_accum(float w, float h, float bd, int best, unsigned long long *sacc, unsigned *scnt,
-                                         unsigned long long &inertia, int &changed, uint8_t *lab)
+                                         unsigned long long &inertia, int &changed, uint8_t *lab, unsigned old)
 {
     atomicAdd(&sacc[(best * 2 + 0) * KM_BLOCK], fx32_biased<FAST>(w));
     atomicAdd(&sacc[(best * 2 + 1) * KM_BLOCK], fx32_biased<FAST>(h));
     atomicAdd(&scnt[best * KM_BLOCK], 1u);
     if (INERTIA) inertia += fx32_biased<FAST>(bd);
-    changed += (*lab != (uint8_t)best);
+    changed += (old != (unsigned)best);          // old label: loaded together with the box, a whole iteration ahead
     *lab = (uint8_t)best;
 }
 
@@ -117,51 +121,104 @@ __device__ __forceinline__ void km_one(float w, float h, const float (&cw)[KMAX]
 {
     float bd;
     const int best = km_assign<KMAX, FULL>(w, h, cw, ch, k, bd);
-    if ((fabsf(w) + fabsf(h)) + fabsf(bd) < KM_FAST_LIMIT) km_accum<true, INERTIA>(w, h, bd, best, sacc, scnt, inertia, changed, lab);
-    else km_accum<false, INERTIA>(w, h, bd, best, sacc, scnt, inertia, changed, lab);
+    if ((fabsf(w) + fabsf(h)) + fabsf(bd) < KM_FAST_LIMIT) km_accum<true, INERTIA>(w, h, bd, best, sacc, scnt, inertia, changed, lab, *lab);
+    else km_accum<false, INERTIA>(w, h, bd, best, sacc, scnt, inertia, changed, lab, *lab);
 }
 
 // INERTIA = false (the iterations of dg_kmeans_iou_run before its last): the sum of distances is not formed, so the
 // winner's exact distance is not evaluated either; acc[3k+1] is then written as 0.  A Lloyd iteration needs the sums,
 // the counts and the changed count; the inertia is reported for the final assignment only (as sklearn does).
-// mode: KM_MODE_STEP  plain step: acc <- this shard's sums, centroids untouched;
-//       KM_MODE_RUN   single-device loop: the last workgroup also moves the centroids by this launch's sums and
-//                     writes history[slot] = this iteration's changed count;
-//       KM_MODE_APPLY sharded loop: `acc` arrives holding the ALL-REDUCED sums of the previous iteration; every
-//                     workgroup first derives this iteration's centroids from (cent, acc) -- the centroid update is the
-//                     prologue of the next step, so an iteration is ONE launch + ONE all-reduce -- and the last
-//                     workgroup writes those centroids back to `cent`, history[slot] = the previous iteration's changed
-//                     count, and acc <- this shard's sums.  In-place is safe: a workgroup draws its ticket after its
-//                     last use of cent / acc, and only the drawer of the last ticket writes them.
-#define KM_MODE_STEP 0
-#define KM_MODE_RUN 1
-#define KM_MODE_APPLY 2
-__device__ __forceinline__ float km_centroid(long long sum, long long cnt)      // as k_kmeans_update / orc_kmeans_update
+// Partial-sums buffer ("part"): KM_REPL rows of km_stride(k) int64, row = {sum_w[k], sum_h[k], count[k], changed,
+// inertia_fx, padding to whole 128-byte lines}.  A launch ADDS into part_out (which must arrive zeroed), reads part_prev
+// (the previous iteration's buffer, all-reduced when sharded; NULL = plain step with the centroids as given) and zeroes
+// part_zero (the buffer the NEXT launch adds into; NULL = nobody needs it).  With three buffers in rotation no zeroing
+// ever races: the buffer zeroed by launch t was last read by launch t-1.
+#define KM_REPL 8
+__host__ __device__ static inline int km_stride(int k) { return ((3 * k + 2) + 15) & ~15; }
+__device__ __forceinline__ float km_centroid(long long sum, long long cnt)      // as k_kmeans_finish / orc_kmeans_update
 {
-    return (float)((double)sum / (double)cnt / 4294967296.0);
+    return (float)(((double)sum / (double)cnt) * 0x1p-32);       // == / 4294967296.0: scaling by a power of two is exact
 }
+
+#ifdef DG_KM_STAMPS
+// diagnostic build only (tools/km_stamps.py): where the first wave of workgroup 0 spends a launch, in 10 ns ticks
+__device__ unsigned long long km_stamps[8];
+__device__ unsigned long long km_blk[1024][2];      // entry / exit time of every workgroup of the last launch
+extern "C" int dg_debug_km_blocks(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(km_blk), sizeof(km_blk)) == hipSuccess ? 0 : -4; }
+#define KM_STAMP(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = __builtin_amdgcn_s_memrealtime(); if (blockIdx.x == 0) { km_stamps[i] = t_; km_stamps[7] = gridDim.x; } \
+                              if ((i) == 0) km_blk[blockIdx.x][0] = t_; if ((i) == 5) km_blk[blockIdx.x][1] = t_; } } while (0)
+extern "C" int dg_debug_km_stamps(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(km_stamps), sizeof(km_stamps)) == hipSuccess ? 0 : -4; }
+#else
+#define KM_STAMP(i)
+#endif
 
 template <int KMAX, bool FULL, bool INERTIA>
 __global__ __launch_bounds__(KM_BLOCK) void k_kmeans_step(const float2 *__restrict__ wh, int64_t n, float *cent, int k,
-                                                          uint8_t *__restrict__ labels, long long *partials, unsigned *ticket,
-                                                          long long *acc, int mode, long long *__restrict__ history,
-                                                          int64_t slot)
+                                                          uint8_t *__restrict__ labels, const long long *part_prev,
+                                                          long long *part_out, long long *part_zero,
+                                                          long long *__restrict__ history, int64_t slot)
 {
-    constexpr int COLS = 3 * KMAX + 2, CP = (COLS + 1) & ~1;      // a row is padded to whole 16-byte pairs
+    constexpr int COLS = 3 * KMAX + 2;
     __shared__ unsigned long long sacc_all[KMAX * 2 * KM_BLOCK];
     __shared__ unsigned scnt_all[KMAX * KM_BLOCK];
-    __shared__ long long red[KM_BLOCK / 64][3 * KMAX + 2];
     __shared__ float2 scent[16];
-    __shared__ long long s_prev_changed;
+    __shared__ long long s_prev[3 * 16 + 2];
     const int tid = threadIdx.x;
+    const int pstride = km_stride(k), cols = 3 * k + 2;
+    KM_STAMP(0);
+    // Every global load the prologue and the first loop iteration need is issued up front, so that their latencies
+    // overlap: the previous sums, the centroids, the first four boxes and their old labels.
+    // two boxes per lane per 16-byte load, two loads in flight; an 8-byte-aligned shard start is peeled off first
+    const int head = ((reinterpret_cast<uintptr_t>(wh) & 8) && n > 0) ? 1 : 0;
+    const float2 *wh_head = wh;
+    wh += head; n -= head;
+    const int64_t npair = n >> 1;
+    const float4 *wh4 = reinterpret_cast<const float4 *>(wh);
+    uint8_t *lab = labels + head;
+    const int64_t stride = (int64_t)gridDim.x * KM_BLOCK;
+    int64_t i = (int64_t)blockIdx.x * KM_BLOCK + tid;
+    bool have = i + stride < npair;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    // the old labels of the four boxes (for the changed count) travel with the boxes: two adjacent bytes per pair
+    auto lab2 = [&](int64_t pair) { return (unsigned)lab[2 * pair] | ((unsigned)lab[2 * pair + 1] << 8); };
+    unsigned la = 0, lb = 0;
+    if (have) { a = wh4[i]; b = wh4[i + stride]; la = lab2(i); lb = lab2(i + stride); }
+    long long pv[KM_REPL];
+#pragma unroll
+    for (int r = 0; r < KM_REPL; ++r) pv[r] = (part_prev && tid < cols) ? part_prev[r * pstride + tid] : 0;
+    float2 c_old = make_float2(0.f, 0.f);
+    if (tid < k) c_old = make_float2(cent[2 * tid], cent[2 * tid + 1]);
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c) {
+        sacc_all[(c * 2 + 0) * KM_BLOCK + tid] = 0;
+        sacc_all[(c * 2 + 1) * KM_BLOCK + tid] = 0;
+        scnt_all[c * KM_BLOCK + tid] = 0;
+    }
+    if (tid < cols) {                                  // fold the previous iteration's replicas: one column per thread
+        long long t = 0;
+#pragma unroll
+        for (int r = 0; r < KM_REPL; ++r) t += pv[r];
+        s_prev[tid] = t;
+    }
+    __syncthreads();
+    KM_STAMP(1);
     if (tid < 16) {
-        float2 c = (tid < k) ? make_float2(cent[2 * tid], cent[2 * tid + 1]) : make_float2(0.f, 0.f);
-        if (mode == KM_MODE_APPLY && tid < k) {
-            const long long cnt = acc[2 * k + tid];
-            if (cnt > 0) { c.x = km_centroid(acc[tid], cnt); c.y = km_centroid(acc[k + tid], cnt); }
+        float2 c = c_old;
+        if (part_prev && tid < k) {
+            const long long cnt = s_prev[2 * k + tid];
+            if (cnt > 0) { c.x = km_centroid(s_prev[tid], cnt); c.y = km_centroid(s_prev[k + tid], cnt); }
         }
         scent[tid] = c;
-        if (tid == 0) s_prev_changed = (mode == KM_MODE_APPLY) ? acc[3 * k] : 0;
+        // bookkeeping by one workgroup.  Writing the derived centroids back in place is safe although other workgroups
+        // may still be reading `cent`: the update is idempotent -- a cluster with members takes its centroid from the
+        // sums alone, an empty one keeps a value this launch does not change -- so a workgroup that reads the new
+        // centroids derives the same ones again.
+        if (blockIdx.x == 0 && part_prev && tid < k) { cent[2 * tid] = c.x; cent[2 * tid + 1] = c.y; }
+    }
+    if (blockIdx.x == 0) {
+        if (part_zero)
+            for (int z = tid; z < KM_REPL * pstride; z += KM_BLOCK) part_zero[z] = 0;
+        if (part_prev && history && tid == 0) history[slot] = s_prev[3 * k];
     }
     __syncthreads();
     float cw[KMAX], ch[KMAX];
@@ -172,38 +229,35 @@ __global__ __launch_bounds__(KM_BLOCK) void k_kmeans_step(const float2 *__restri
         cw[c] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(scent[c < 16 ? c : 0].x)));
         ch[c] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(scent[c < 16 ? c : 0].y)));
         cent_ok = cent_ok && (fabsf(cw[c] * ch[c]) < 0x1p60f);
-        sacc_all[(c * 2 + 0) * KM_BLOCK + tid] = 0;
-        sacc_all[(c * 2 + 1) * KM_BLOCK + tid] = 0;
-        scnt_all[c * KM_BLOCK + tid] = 0;
     }
-    __syncthreads();
+    KM_STAMP(2);
     const unsigned gap_min = cent_ok ? KM_GAP_MIN : 0xffffffffu;     // a gap nobody reaches: exact path only
     unsigned long long *sacc = sacc_all + tid;     // lane-private column: no barrier needed until the final reduce
     unsigned *scnt = scnt_all + tid;
     unsigned long long inertia = 0;                // biased like the LDS sums: KM_MAGIC per box
     int changed = 0;
 
-    // two boxes per lane per 16-byte load, two loads in flight; an 8-byte-aligned shard start is peeled off first
-    const int head = ((reinterpret_cast<uintptr_t>(wh) & 8) && n > 0) ? 1 : 0;
     if (head && blockIdx.x == 0 && tid == 0) {
-        const float2 t = wh[0];
+        const float2 t = wh_head[0];
         km_one<KMAX, FULL, INERTIA>(t.x, t.y, cw, ch, k, sacc, scnt, inertia, changed, labels);
     }
-    wh += head; n -= head;
-    const int64_t npair = n >> 1;
-    const float4 *wh4 = reinterpret_cast<const float4 *>(wh);
-    uint8_t *lab = labels + head;
-    const int64_t stride = (int64_t)gridDim.x * KM_BLOCK;
-    int64_t i = (int64_t)blockIdx.x * KM_BLOCK + tid;
-    bool have = i + stride < npair;
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
-    if (have) { a = wh4[i]; b = wh4[i + stride]; }
+    // Waves that share a SIMD are served oldest first, so the workgroup that reached a CU first would finish its (equal)
+    // share first and leave the youngest alone on the SIMD at half the issue rate.  Rotating the priority every pass
+    // gives every wave each level equally often (priority outranks age) and they finish together.
+    unsigned prio = (blockIdx.x >> 8);
     while (have) {
+        switch ((prio++) & 3u) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+        }
         // the next pair of loads is issued before this pair is worked on
         const int64_t inext = i + 2 * stride;
         const bool more = inext + stride < npair;
         float4 na = a, nb = b;
-        if (more) { na = wh4[inext]; nb = wh4[inext + stride]; }
+        unsigned nla = 0, nlb = 0;
+        if (more) { na = wh4[inext]; nb = wh4[inext + stride]; nla = lab2(inext); nlb = lab2(inext + stride); }
         float d0, d1, d2, d3;
         int b0, b1, b2, b3;
         const float magwh = ((fabsf(a.x) + fabsf(a.y)) + (fabsf(a.z) + fabsf(a.w))) + ((fabsf(b.x) + fabsf(b.y)) + (fabsf(b.z) + fabsf(b.w)));
@@ -224,20 +278,22 @@ __global__ __launch_bounds__(KM_BLOCK) void k_kmeans_step(const float2 *__restri
         // one range test for the four boxes: every term is >= 0, so a sum below the limit bounds each of them
         const float mag = magwh + ((fabsf(d0) + fabsf(d1)) + (fabsf(d2) + fabsf(d3)));
         if (mag < KM_FAST_LIMIT) {
-            km_accum<true, INERTIA>(a.x, a.y, d0, b0, sacc, scnt, inertia, changed, lab + 2 * i);
-            km_accum<true, INERTIA>(a.z, a.w, d1, b1, sacc, scnt, inertia, changed, lab + 2 * i + 1);
-            km_accum<true, INERTIA>(b.x, b.y, d2, b2, sacc, scnt, inertia, changed, lab + 2 * (i + stride));
-            km_accum<true, INERTIA>(b.z, b.w, d3, b3, sacc, scnt, inertia, changed, lab + 2 * (i + stride) + 1);
+            km_accum<true, INERTIA>(a.x, a.y, d0, b0, sacc, scnt, inertia, changed, lab + 2 * i, la & 255u);
+            km_accum<true, INERTIA>(a.z, a.w, d1, b1, sacc, scnt, inertia, changed, lab + 2 * i + 1, la >> 8);
+            km_accum<true, INERTIA>(b.x, b.y, d2, b2, sacc, scnt, inertia, changed, lab + 2 * (i + stride), lb & 255u);
+            km_accum<true, INERTIA>(b.z, b.w, d3, b3, sacc, scnt, inertia, changed, lab + 2 * (i + stride) + 1, lb >> 8);
         } else {
-            km_accum<false, INERTIA>(a.x, a.y, d0, b0, sacc, scnt, inertia, changed, lab + 2 * i);
-            km_accum<false, INERTIA>(a.z, a.w, d1, b1, sacc, scnt, inertia, changed, lab + 2 * i + 1);
-            km_accum<false, INERTIA>(b.x, b.y, d2, b2, sacc, scnt, inertia, changed, lab + 2 * (i + stride));
-            km_accum<false, INERTIA>(b.z, b.w, d3, b3, sacc, scnt, inertia, changed, lab + 2 * (i + stride) + 1);
+            km_accum<false, INERTIA>(a.x, a.y, d0, b0, sacc, scnt, inertia, changed, lab + 2 * i, la & 255u);
+            km_accum<false, INERTIA>(a.z, a.w, d1, b1, sacc, scnt, inertia, changed, lab + 2 * i + 1, la >> 8);
+            km_accum<false, INERTIA>(b.x, b.y, d2, b2, sacc, scnt, inertia, changed, lab + 2 * (i + stride), lb & 255u);
+            km_accum<false, INERTIA>(b.z, b.w, d3, b3, sacc, scnt, inertia, changed, lab + 2 * (i + stride) + 1, lb >> 8);
         }
-        i = inext; a = na; b = nb; have = more;
+        i = inext; a = na; b = nb; la = nla; lb = nlb; have = more;
     }
+    __builtin_amdgcn_s_setprio(0);
     for (; i < npair; i += stride) {                     // what the four-box loop leaves: same scheme, two boxes
         const float4 t = wh4[i];
+        const unsigned lt = lab2(i);
         float d0, d1;
         int b0, b1;
         const float magwh = (fabsf(t.x) + fabsf(t.y)) + (fabsf(t.z) + fabsf(t.w));
@@ -253,11 +309,11 @@ __global__ __launch_bounds__(KM_BLOCK) void k_kmeans_step(const float2 *__restri
             b0 = km_assign<KMAX, FULL>(t.x, t.y, cw, ch, k, d0); b1 = km_assign<KMAX, FULL>(t.z, t.w, cw, ch, k, d1);
         }
         if (magwh + (fabsf(d0) + fabsf(d1)) < KM_FAST_LIMIT) {
-            km_accum<true, INERTIA>(t.x, t.y, d0, b0, sacc, scnt, inertia, changed, lab + 2 * i);
-            km_accum<true, INERTIA>(t.z, t.w, d1, b1, sacc, scnt, inertia, changed, lab + 2 * i + 1);
+            km_accum<true, INERTIA>(t.x, t.y, d0, b0, sacc, scnt, inertia, changed, lab + 2 * i, lt & 255u);
+            km_accum<true, INERTIA>(t.z, t.w, d1, b1, sacc, scnt, inertia, changed, lab + 2 * i + 1, lt >> 8);
         } else {
-            km_accum<false, INERTIA>(t.x, t.y, d0, b0, sacc, scnt, inertia, changed, lab + 2 * i);
-            km_accum<false, INERTIA>(t.z, t.w, d1, b1, sacc, scnt, inertia, changed, lab + 2 * i + 1);
+            km_accum<false, INERTIA>(t.x, t.y, d0, b0, sacc, scnt, inertia, changed, lab + 2 * i, lt & 255u);
+            km_accum<false, INERTIA>(t.z, t.w, d1, b1, sacc, scnt, inertia, changed, lab + 2 * i + 1, lt >> 8);
         }
     }
     if ((n & 1) && blockIdx.x == 0 && tid == 0) {
@@ -265,111 +321,88 @@ __global__ __launch_bounds__(KM_BLOCK) void k_kmeans_step(const float2 *__restri
         km_one<KMAX, FULL, INERTIA>(t.x, t.y, cw, ch, k, sacc, scnt, inertia, changed, lab + (n - 1));
     }
 
-    // block reduction: wave shuffles, then LDS across the 4 waves
-    const int lane = tid & 63, wave = tid >> 6;
-    long long nbox = 0;
+    KM_STAMP(3);
+    // Block reduction through LDS, no shuffles (17 x 64-bit wave reductions by ds_bpermute took 3.5 us per launch): the
+    // accumulators already sit in LDS as [column][thread]; 16 threads sum one column's 256 entries (16 each), a second
+    // step sums the 16 partials.  red[] is reused: [COLS][16] partials.
+    static_assert(KM_BLOCK == 256, "16 threads x 16 entries per column");
+    __shared__ unsigned long long s_inertia[KM_BLOCK];
+    __shared__ unsigned s_changed[KM_BLOCK];
+    __shared__ unsigned long long s_cpart[COLS][16];
+    // `inertia` carries KM_MAGIC per box this thread accumulated (mod 2^64): taken off here, with the thread's own counts
+    if (INERTIA) {
+        unsigned mine = 0;
 #pragma unroll
-    for (int c = 0; c < KMAX; ++c) {
-        long long a = wave_sum_ll((long long)sacc[(c * 2 + 0) * KM_BLOCK]), b2 = wave_sum_ll((long long)sacc[(c * 2 + 1) * KM_BLOCK]);
-        long long c2 = wave_sum_ll((long long)scnt[c * KM_BLOCK]);
-        const long long bias = (long long)((unsigned long long)c2 * KM_MAGIC);   // mod 2^64, like the sums
-        nbox += c2;
-        if (lane == 0) { red[wave][c] = a - bias; red[wave][KMAX + c] = b2 - bias; red[wave][2 * KMAX + c] = c2; }
+        for (int c = 0; c < KMAX; ++c) mine += scnt[c * KM_BLOCK];
+        inertia -= (unsigned long long)mine * KM_MAGIC;
     }
-    {
-        long long a = wave_sum_ll((long long)changed), b2 = wave_sum_ll((long long)inertia);
-        if (lane == 0) { red[wave][3 * KMAX] = a; red[wave][3 * KMAX + 1] = INERTIA ? b2 - (long long)((unsigned long long)nbox * KM_MAGIC) : 0; }
-    }
-    __syncthreads();
-    if (tid < CP) {
-        long long v = 0;
-        if (tid < COLS) {
-#pragma unroll
-            for (int w = 0; w < KM_BLOCK / 64; ++w) v += red[w][tid];
-        }
-        // Device-scope (write-through) store, completed before the ticket is drawn.  A __threadfence() here costs a
-        // sweep of the XCD's whole L2 per workgroup (+24 us per launch when every workgroup does one).
-        __hip_atomic_store(&partials[(int64_t)blockIdx.x * CP + tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-
-    // The workgroup that draws the last ticket folds all rows (and, inside dg_kmeans_iou_run, moves the centroids):
-    // one launch per Lloyd iteration instead of three.  The ticket returns to zero for the next launch.
-    __shared__ unsigned s_ticket;
-    __syncthreads();
-    if (tid == 0) s_ticket = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();
-    if (s_ticket != gridDim.x - 1) return;
-    unsigned long long *s_tot = sacc_all;                  // the accumulators are spent; reuse their LDS
-    if (tid < CP) s_tot[tid] = 0;
+    s_inertia[tid] = INERTIA ? inertia : 0ull;
+    s_changed[tid] = (unsigned)changed;
     __syncthreads();
     {
-        // Device-scope loads (sc1): the rows were written from every XCD and must not come from this XCD's L2.
-        // Thirty-two are issued before the first is used; as atomic loads the compiler would wait for each in turn.
-        // A thread strides by a multiple of the row length, so all its values belong to one column and meet in a register.
-        constexpr int ACTIVE = (KM_BLOCK / CP) * CP;
-        const int nvals = (int)gridDim.x * CP;
-        if (tid < ACTIVE) {
-            long long sum = 0;
-            for (int base = tid; base < nvals; base += 32 * ACTIVE) {
-                long long v[32];
+        const int sub = tid & 15;
+        for (int col = tid >> 4; col < COLS; col += KM_BLOCK / 16) {
+            unsigned long long t = 0;
+            if (col < 2 * KMAX) {
+                const unsigned long long *src = sacc_all + ((col % KMAX) * 2 + col / KMAX) * KM_BLOCK;
 #pragma unroll
-                for (int j = 0; j < 32; ++j) {
-                    const int p = base + j * ACTIVE;
-                    const long long *ptr = partials + (p < nvals ? p : 0);
-                    asm volatile("global_load_dwordx2 %0, %1, off sc1" : "=&v"(v[j]) : "v"(ptr) : "memory");
-                }
-                asm volatile("s_waitcnt vmcnt(0)"
-                             : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
-                               "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15])
-                             :
-                             : "memory");
-                asm volatile(""
-                             : "+v"(v[16]), "+v"(v[17]), "+v"(v[18]), "+v"(v[19]), "+v"(v[20]), "+v"(v[21]), "+v"(v[22]), "+v"(v[23]),
-                               "+v"(v[24]), "+v"(v[25]), "+v"(v[26]), "+v"(v[27]), "+v"(v[28]), "+v"(v[29]), "+v"(v[30]), "+v"(v[31])
-                             :
-                             : "memory");
+                for (int j = 0; j < 16; ++j) t += src[j * 16 + sub];
+            } else if (col < 3 * KMAX) {
+                const unsigned *src = scnt_all + (col - 2 * KMAX) * KM_BLOCK;
 #pragma unroll
-                for (int j = 0; j < 32; ++j) sum += (base + j * ACTIVE < nvals) ? v[j] : 0;
+                for (int j = 0; j < 16; ++j) t += src[j * 16 + sub];
+            } else if (col == 3 * KMAX) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) t += s_changed[j * 16 + sub];
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) t += s_inertia[j * 16 + sub];
             }
-            atomicAdd(&s_tot[tid % CP], (unsigned long long)sum);
+            s_cpart[col][sub] = t;
         }
     }
     __syncthreads();
+    KM_STAMP(4);
     if (tid < COLS) {
-        const long long t = (long long)s_tot[tid];
+        unsigned long long v = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v += s_cpart[tid][j];
         const int grp = tid / KMAX, c = tid - grp * KMAX;
-        if (grp < 3) { if (c < k) acc[grp * k + c] = t; }
-        else acc[3 * k + c] = t;                           // changed, inertia
-    }
-    if (mode == KM_MODE_RUN) {                             // same arithmetic as k_kmeans_update
-        if (tid < k) {
-            const long long cnt = (long long)s_tot[2 * KMAX + tid];
-            if (cnt > 0) {
-                cent[2 * tid] = km_centroid((long long)s_tot[tid], cnt);
-                cent[2 * tid + 1] = km_centroid((long long)s_tot[KMAX + tid], cnt);
-            }
+        // the fixed-point sums carry KM_MAGIC per box (mod 2^64): taken off with the cluster's count / the box count
+        if (grp < 2) {
+            unsigned long long cnt = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) cnt += s_cpart[2 * KMAX + c][j];
+            v -= cnt * KM_MAGIC;
         }
-        if (tid == 0 && history) history[slot] = (long long)s_tot[3 * KMAX];
-    } else if (mode == KM_MODE_APPLY) {                    // the centroids this launch derived and used
-        if (tid < k) { cent[2 * tid] = scent[tid].x; cent[2 * tid + 1] = scent[tid].y; }
-        if (tid == 0 && history) history[slot] = s_prev_changed;
+        // this workgroup's row into its replica: 64-bit no-return atomics (device scope); the next launch on the stream
+        // reads the sums with plain loads
+        const int col = (grp < 3) ? (c < k ? grp * k + c : -1) : 3 * k + c;
+        if (col >= 0 && v != 0)
+            atomicAdd(reinterpret_cast<unsigned long long *>(part_out) + (blockIdx.x % KM_REPL) * pstride + col, v);
     }
-    if (tid == 0) *ticket = 0;
+    KM_STAMP(5);
 }
 
-__global__ void k_kmeans_update(const long long *__restrict__ acc, int k, float *__restrict__ cent,
-                                long long *__restrict__ history, int64_t slot)
+// folds the replicas of the last iteration (all-reduced when sharded): acc_out[3k+2] = the sums (may be NULL),
+// centroid = sum/count (int64 fixed point 2^32 -> fp32; an empty cluster keeps its centroid), history[slot] = changed
+__global__ __launch_bounds__(64) void k_kmeans_finish(const long long *__restrict__ part, int k, float *__restrict__ cent,
+                                                      long long *__restrict__ acc_out, long long *__restrict__ history, int64_t slot)
 {
-    const int c = threadIdx.x;
-    if (c < k) {
-        long long cnt = acc[2 * k + c];
-        if (cnt > 0) {
-            cent[2 * c] = (float)((double)acc[c] / (double)cnt / 4294967296.0);
-            cent[2 * c + 1] = (float)((double)acc[k + c] / (double)cnt / 4294967296.0);
-        }
+    __shared__ long long s[3 * 16 + 2];
+    const int tid = threadIdx.x, stride = km_stride(k), cols = 3 * k + 2;
+    if (tid < cols) {
+        long long t = 0;
+        for (int r = 0; r < KM_REPL; ++r) t += part[r * stride + tid];
+        s[tid] = t;
+        if (acc_out) acc_out[tid] = t;
     }
-    if (c == 0 && history) history[slot] = acc[3 * k];
+    __syncthreads();
+    if (cent && tid < k) {
+        const long long cnt = s[2 * k + tid];
+        if (cnt > 0) { cent[2 * tid] = km_centroid(s[tid], cnt); cent[2 * tid + 1] = km_centroid(s[k + tid], cnt); }
+    }
+    if (tid == 0 && history) history[slot] = s[3 * k];
 }
 
 __global__ __launch_bounds__(256) void k_labels_widen(const uint8_t *__restrict__ l, int64_t n, int32_t *__restrict__ out)
@@ -393,31 +426,35 @@ static int km_resident_blocks(K kernel)
 }
 static inline int km_blocks(int64_t n, int resident)
 {
-    // at least 16 boxes per thread: a small shard (1.25 M boxes) runs 16 us with 305 workgroups and 26 us with 1024,
-    // whose prologues and partial rows (folded by the last workgroup) then outweigh the boxes
-    int64_t b = dg_cdiv(n, KM_BLOCK * 16);
+    // at least 4 boxes per thread (one pass of the four-box loop); measured on 1.25 M boxes: 16 per thread 10.1 us, 8: 9.0, 4: 8.6
+    static const int bpt = getenv("DG_KM_BPT") ? atoi(getenv("DG_KM_BPT")) : 4;
+    int64_t b = dg_cdiv(n, KM_BLOCK * bpt);
     return (int)(b < 1 ? 1 : (b > resident ? resident : b));
 }
 
+extern "C" size_t dg_kmeans_part_elems(int64_t k)
+{
+    if (k <= 0 || k > 16) return 0;
+    return (size_t)KM_REPL * km_stride((int)k);
+}
+// workspace of dg_kmeans_iou_step / dg_kmeans_iou_run: three partial-sums buffers in rotation
 extern "C" size_t dg_kmeans_workspace_bytes(int64_t n, int64_t k)
 {
     if (n < 0 || k <= 0 || k > 16) return 0;
-    return (size_t)KM_MAXBLOCKS * (3 * 16 + 2) * 8 + 16;     // rows + the ticket
+    return 3 * dg_kmeans_part_elems(k) * 8;
 }
-static inline unsigned *km_ticket(void *ws) { return (unsigned *)((char *)ws + (size_t)KM_MAXBLOCKS * (3 * 16 + 2) * 8); }
 
-// step (+ fold) as one launch; with cent_out the last workgroup also writes the new centroids and history[slot]
-static int km_launch(const float *wh, int64_t n, float *cent, int64_t k, uint8_t *labels, int64_t *acc, int mode,
-                     int64_t *history, int64_t slot, bool inertia, void *ws, hipStream_t st)
+// one launch: [centroids <- part_prev;] step; part_out += this shard's rows; part_zero <- 0
+static int km_launch(const float *wh, int64_t n, float *cent, int64_t k, uint8_t *labels, const int64_t *part_prev, int64_t *part_out,
+                     int64_t *part_zero, int64_t *history, int64_t slot, bool inertia, hipStream_t st)
 {
     const int kmax = km_kmax(k);
-    long long *partials = (long long *)ws;
 #define KM_LAUNCH1(KM, FULL, INERTIA)                                                                                           \
     do {                                                                                                                        \
         static const int resident = km_resident_blocks(k_kmeans_step<KM, FULL, INERTIA>);                                       \
         hipLaunchKernelGGL((k_kmeans_step<KM, FULL, INERTIA>), dim3(km_blocks(n, resident)), dim3(KM_BLOCK), 0, st,             \
-                           (const float2 *)wh, n, cent, (int)k, labels, partials, km_ticket(ws), (long long *)acc, mode,        \
-                           (long long *)history, slot);                                                                         \
+                           (const float2 *)wh, n, cent, (int)k, labels, (const long long *)part_prev, (long long *)part_out,    \
+                           (long long *)part_zero, (long long *)history, slot);                                                 \
     } while (0)
 #define KM_LAUNCH(KM, FULL)                                                                                                     \
     do {                                                                                                                        \
@@ -436,55 +473,60 @@ static int km_launch(const float *wh, int64_t n, float *cent, int64_t k, uint8_t
     return DG_OK;
 }
 
-static int km_check(const float *wh, int64_t n, const float *cent, int64_t k, const uint8_t *labels, const int64_t *acc, const void *ws,
-                    size_t ws_bytes)
+static int km_check(const char *fn, const float *wh, int64_t n, const float *cent, int64_t k, const uint8_t *labels)
 {
-    DG_REQUIRE(n >= 0 && k >= 1 && k <= 16, "kmeans_step: need n >= 0 and 1 <= k <= 16");
-    DG_REQUIRE(cent && acc && ws, "kmeans_step: null pointer");
-    DG_REQUIRE(n == 0 || (wh && labels), "kmeans_step: null pointer");
-    DG_REQUIRE((((uintptr_t)wh) & 7) == 0 && (((uintptr_t)ws) & 15) == 0, "kmeans_step: misaligned pointer");
-    if (ws_bytes < dg_kmeans_workspace_bytes(n, k)) { dg_set_error("kmeans_step: workspace too small"); return DG_ENOMEM; }
+    DG_REQUIRE(n >= 0 && k >= 1 && k <= 16, "%s: need n >= 0 and 1 <= k <= 16", fn);
+    DG_REQUIRE(cent, "%s: null centroids", fn);
+    DG_REQUIRE(n == 0 || (wh && labels), "%s: null pointer", fn);
+    DG_REQUIRE((((uintptr_t)wh) & 7) == 0, "%s: wh must be 8-byte aligned", fn);
+    return DG_OK;
+}
+static int km_check_ws(const char *fn, int64_t n, int64_t k, const void *ws, size_t ws_bytes)
+{
+    DG_REQUIRE(ws && (((uintptr_t)ws) & 15) == 0, "%s: workspace null or misaligned", fn);
+    if (ws_bytes < dg_kmeans_workspace_bytes(n, k)) { dg_set_error("%s: workspace too small", fn); return DG_ENOMEM; }
+    return DG_OK;
+}
+static int km_finish(const int64_t *part, int64_t k, float *cent, int64_t *acc_out, int64_t *history, int64_t slot, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_kmeans_finish, dim3(1), dim3(64), 0, st, (const long long *)part, (int)k, cent, (long long *)acc_out,
+                       (long long *)history, slot);
+    DG_CHECK_LAUNCH("k_kmeans_finish");
     return DG_OK;
 }
 
 extern "C" int dg_kmeans_iou_step(const float *wh, int64_t n, const float *cent, int64_t k, uint8_t *labels, int64_t *acc,
                                   void *ws, size_t ws_bytes, dg_stream_t s)
 {
-    int rc = km_check(wh, n, cent, k, labels, acc, ws, ws_bytes);
+    int rc = km_check("kmeans_step", wh, n, cent, k, labels);
     if (rc) return rc;
+    DG_REQUIRE(acc, "kmeans_step: null acc");
+    if ((rc = km_check_ws("kmeans_step", n, k, ws, ws_bytes))) return rc;
     hipStream_t st = (hipStream_t)s;
+    int64_t *part = (int64_t *)ws;
     // the workspace arrives with arbitrary contents
-    if (hipMemsetAsync(km_ticket(ws), 0, 16, st) != hipSuccess) { dg_set_error("kmeans_step: memset failed"); return DG_EHIP; }
-    return km_launch(wh, n, const_cast<float *>(cent), k, labels, acc, KM_MODE_STEP, nullptr, 0, true, ws, st);
+    if (hipMemsetAsync(part, 0, dg_kmeans_part_elems(k) * 8, st) != hipSuccess) { dg_set_error("kmeans_step: memset failed"); return DG_EHIP; }
+    if ((rc = km_launch(wh, n, const_cast<float *>(cent), k, labels, nullptr, part, nullptr, nullptr, 0, true, st))) return rc;
+    return km_finish(part, k, nullptr, acc, nullptr, 0, st);
 }
 
-// One iteration of the SHARDED Lloyd loop as one launch (KM_MODE_APPLY above).  apply_prev != 0: acc holds the
-// all-reduced sums of the previous iteration; the centroids are first moved by them (empty cluster keeps its centroid),
-// written back to `cent`, and history[slot] (may be NULL) receives the previous iteration's changed count.  Then the
-// step runs and acc is overwritten with this shard's sums: all-reduce it and call again.  After the last iteration,
-// dg_kmeans_update applies the last sums.  want_inertia == 0 leaves acc[3k+1] = 0 (a Lloyd iteration does not use it).
-// A call with apply_prev != 0 must follow another dg_kmeans_iou_iter call on the same workspace, stream-ordered, with
-// nothing else using that workspace in between (the launch ticket in it is cleared by apply_prev == 0 calls only).
-extern "C" int dg_kmeans_iou_iter(const float *wh, int64_t n, float *cent, int64_t k, uint8_t *labels, int64_t *acc,
-                                  int apply_prev, int want_inertia, int64_t *history, int64_t slot, void *ws,
-                                  size_t ws_bytes, dg_stream_t s)
+// One iteration of the SHARDED Lloyd loop as one launch (declaration: include/detgeom.h).
+extern "C" int dg_kmeans_iou_iter(const float *wh, int64_t n, float *cent, int64_t k, uint8_t *labels, const int64_t *part_prev,
+                                  int64_t *part_out, int64_t *part_zero, int want_inertia, int64_t *history, int64_t slot,
+                                  dg_stream_t s)
 {
-    int rc = km_check(wh, n, cent, k, labels, acc, ws, ws_bytes);
+    int rc = km_check("kmeans_iter", wh, n, cent, k, labels);
     if (rc) return rc;
-    hipStream_t st = (hipStream_t)s;
-    // the ticket returns to zero at the end of every launch: only the first call of a sequence has to clear it
-    if (!apply_prev && hipMemsetAsync(km_ticket(ws), 0, 16, st) != hipSuccess) { dg_set_error("kmeans_iter: memset failed"); return DG_EHIP; }
-    return km_launch(wh, n, cent, k, labels, acc, apply_prev ? KM_MODE_APPLY : KM_MODE_STEP, apply_prev ? history : nullptr,
-                     slot, want_inertia != 0, ws, st);
+    DG_REQUIRE(part_out && part_out != part_prev && part_zero != part_out && (part_zero == nullptr || part_zero != part_prev),
+               "kmeans_iter: part_out must be given and the three buffers must differ");
+    return km_launch(wh, n, cent, k, labels, part_prev, part_out, part_zero, history, slot, want_inertia != 0, (hipStream_t)s);
 }
 
-extern "C" int dg_kmeans_update(const int64_t *acc, int64_t k, float *cent, int64_t *history, int64_t slot, dg_stream_t s)
+extern "C" int dg_kmeans_finish(const int64_t *part, int64_t k, float *cent, int64_t *acc_out, int64_t *history, int64_t slot,
+                                dg_stream_t s)
 {
-    DG_REQUIRE(k >= 1 && k <= 16 && acc && cent, "kmeans_update: bad argument");
-    hipLaunchKernelGGL(k_kmeans_update, dim3(1), dim3(64), 0, (hipStream_t)s, (const long long *)acc, (int)k, cent,
-                       (long long *)history, slot);
-    DG_CHECK_LAUNCH("k_kmeans_update");
-    return DG_OK;
+    DG_REQUIRE(k >= 1 && k <= 16 && part, "kmeans_finish: bad argument");
+    return km_finish(part, k, cent, acc_out, history, slot, (hipStream_t)s);
 }
 
 // `iters` Lloyd iterations back to back on one device (one launch per iteration, no host round trip);
@@ -494,16 +536,22 @@ extern "C" int dg_kmeans_iou_run(const float *wh, int64_t n, float *cent, int64_
                                  int64_t *history, int64_t slot0, int64_t iters, void *ws, size_t ws_bytes, dg_stream_t s)
 {
     DG_REQUIRE(iters >= 0, "kmeans_run: iters < 0");
-    int rc = km_check(wh, n, cent, k, labels, acc, ws, ws_bytes);
+    int rc = km_check("kmeans_run", wh, n, cent, k, labels);
     if (rc) return rc;
+    DG_REQUIRE(acc, "kmeans_run: null acc");
+    if ((rc = km_check_ws("kmeans_run", n, k, ws, ws_bytes))) return rc;
     if (iters == 0) return DG_OK;
     hipStream_t st = (hipStream_t)s;
-    if (hipMemsetAsync(km_ticket(ws), 0, 16, st) != hipSuccess) { dg_set_error("kmeans_run: memset failed"); return DG_EHIP; }
+    const size_t pe = dg_kmeans_part_elems(k);
+    int64_t *part[3] = {(int64_t *)ws, (int64_t *)ws + pe, (int64_t *)ws + 2 * pe};
+    if (hipMemsetAsync(ws, 0, 3 * pe * 8, st) != hipSuccess) { dg_set_error("kmeans_run: memset failed"); return DG_EHIP; }
     for (int64_t t = 0; t < iters; ++t) {
-        rc = km_launch(wh, n, cent, k, labels, acc, KM_MODE_RUN, history, slot0 + t, t + 1 == iters, ws, st);   // inertia: last only
+        // launch t: centroids <- sums of t-1 (and history[slot0+t-1]); adds into buffer t%3; zeroes buffer (t+1)%3
+        rc = km_launch(wh, n, cent, k, labels, t ? part[(t - 1) % 3] : nullptr, part[t % 3], part[(t + 1) % 3], history, slot0 + t - 1,
+                       t + 1 == iters, st);                                        // inertia: last iteration only
         if (rc) return rc;
     }
-    return DG_OK;
+    return km_finish(part[(iters - 1) % 3], k, cent, acc, history, slot0 + iters - 1, st);
 }
 
 extern "C" int dg_kmeans_labels_i32(const uint8_t *labels, int64_t n, int32_t *out, dg_stream_t s)

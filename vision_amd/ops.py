@@ -290,11 +290,11 @@ def kmeans_run(wh, cent, labels, acc, history, slot0, iters):
                                        stream_ptr(dev)))
 
 
-def kmeans_update(acc, cent, history=None, slot=0):
-    dev = cent.device
+def kmeans_finish(part, k, cent=None, acc_out=None, history=None, slot=0):
+    """fold a partial-sums buffer (all-reduced when sharded): acc_out <- sums, cent moved by them, history[slot] <- changed"""
+    dev = part.device
     with torch.cuda.device(dev):
-        check(load().dg_kmeans_update(ptr(acc), cent.shape[0], ptr(cent), ptr(history), slot, stream_ptr(dev)))
-    return cent
+        check(load().dg_kmeans_finish(ptr(part), k, ptr(cent), ptr(acc_out), ptr(history), slot, stream_ptr(dev)))
 
 
 def kmeans_labels_i32(labels_u8):
