@@ -13,8 +13,12 @@
 // image's RoI list reading grad_out/argmax as contiguous runs, accumulates with LDS float atomics
 // and writes the slice out once: no global atomics, grad_in written exactly once.
 #include "common.hpp"
+#include <stdlib.h>
 
 #define RP 7
+#ifndef DG_BWD_XCD_REMAP
+#define DG_BWD_XCD_REMAP 1
+#endif
 #define RBINS 49
 
 // ---------------------------------------------------------------- windows (:366-369 + python slicing)
@@ -784,7 +788,13 @@ __global__ __launch_bounds__(NT) void k_roipool_bwd(const float *__restrict__ gr
         return *reinterpret_cast<const int4 *>(argmax + o);
     };
     const int tid = threadIdx.x;
-    const int b = blockIdx.y, c0 = blockIdx.x * CB;
+    // blockIdx.x -> channel slice.  Workgroups are dealt round-robin over the 8 XCDs and gridDim.x is the fastest index, so
+    // with the identity mapping neighbouring slices -- whose 784-byte pieces of every RoI share a 128-byte line -- always
+    // sit on different XCDs and that line is fetched from memory twice.  When gridDim.x is a multiple of 8, XCD j takes
+    // the contiguous slices [j*gridDim.x/8, (j+1)*gridDim.x/8): neighbours run side by side under one L2.
+    const int nsl = gridDim.x;
+    const int slice = (nsl % 8 == 0 && DG_BWD_XCD_REMAP) ? (int)(blockIdx.x % 8) * (nsl / 8) + (int)(blockIdx.x / 8) : (int)blockIdx.x;
+    const int b = blockIdx.y, c0 = slice * CB;
     const int cb = (C - c0) < CB ? (C - c0) : CB;
     const int HW = H * W;
     for (int i = tid; i < cb * HW; i += NT) plane[i] = 0.f;
@@ -1097,6 +1107,14 @@ static int roipool_bwd(const float *grad_out, const void *argmax, bool a16, cons
     int CB = 1;
     while (CB < 4 && (int64_t)CB * 2 * HW * 4 <= 32 * 1024 && CB * 2 <= C) CB *= 2;      // 4 channels: 16-byte vector path
     while (mode == DG_POOL_MAX && CB < 16 && (int64_t)CB * 2 * HW * 4 <= 32 * 1024 && B * dg_cdiv(C, CB * 2) >= 1024) CB *= 2;
+    // Max mode with enough images: one 1024-thread workgroup per (image, 16 channels) -- 3136 contiguous bytes of
+    // grad_out / argmax per RoI, so only 1 line in 25 is shared with a neighbour (4-channel slices: 784 bytes, 1 in 7, and
+    // FETCH_SIZE read 1.17x the algorithmic bytes); the 16 planes take 16*H*W*4 bytes of LDS (121.6 KB at 38x50), one
+    // workgroup per CU.  Measured at 256 images x 2000 RoIs: 18.9 ms (4 channels, 256 threads) -> 18.1 (8, 512) -> 17.6
+    // (16, 1024); the wider slices with 256 threads: 27.7 ms (too few waves per CU).
+    int NT = 256;
+    if (mode == DG_POOL_MAX && C % 16 == 0 && (int64_t)16 * HW * 4 <= 144 * 1024 && B * (C / 16) >= 256) { CB = 16; NT = 1024; }
+    else if (mode == DG_POOL_MAX && C % 8 == 0 && (int64_t)8 * HW * 4 <= 72 * 1024 && B * (C / 8) >= 512) { CB = 8; NT = 512; }
     int64_t S = 1;                                     // RoI-list splits when there are too few (image, slice) pairs
     while (S < 16 && B * dg_cdiv(C, CB) * S < 1024 && n / (B * S * 2) >= 64) S *= 2;
     dim3 grid((unsigned)dg_cdiv(C, CB), (unsigned)B, (unsigned)S);
@@ -1107,7 +1125,9 @@ static int roipool_bwd(const float *grad_out, const void *argmax, bool a16, cons
                      (((uintptr_t)argmax) & (a16 ? 7 : 15)) == 0;
 #define BWD_LAUNCH(MODE, VEC, NT, A16) \
     hipLaunchKernelGGL((k_roipool_bwd<MODE, VEC, NT, A16>), grid, dim3(NT), lds, st, grad_out, argmax, win, w.off, w.list, (int)C, (int)H, (int)W, CB, grad_in)
-    if (mode == DG_POOL_MAX && vec) { if (a16) BWD_LAUNCH(DG_POOL_MAX, true, 256, true); else BWD_LAUNCH(DG_POOL_MAX, true, 256, false); }
+    if (mode == DG_POOL_MAX && vec && NT == 512) { if (a16) BWD_LAUNCH(DG_POOL_MAX, true, 512, true); else BWD_LAUNCH(DG_POOL_MAX, true, 512, false); }
+    else if (mode == DG_POOL_MAX && vec && NT == 1024) { if (a16) BWD_LAUNCH(DG_POOL_MAX, true, 1024, true); else BWD_LAUNCH(DG_POOL_MAX, true, 1024, false); }
+    else if (mode == DG_POOL_MAX && vec) { if (a16) BWD_LAUNCH(DG_POOL_MAX, true, 256, true); else BWD_LAUNCH(DG_POOL_MAX, true, 256, false); }
     else if (mode == DG_POOL_MAX) { if (a16) BWD_LAUNCH(DG_POOL_MAX, false, 256, true); else BWD_LAUNCH(DG_POOL_MAX, false, 256, false); }
     else BWD_LAUNCH(DG_POOL_AVG, false, 512, false);
 #undef BWD_LAUNCH
