@@ -132,12 +132,19 @@ int dg_roi_windows(const double *rois, const int64_t *roi_idx, int64_t n, int64_
 int dg_nchw_to_nhwc_f32(const float *src, int64_t B, int64_t C, int64_t H, int64_t W, float *dst, int32_t *nan_flag,
                         dg_stream_t s);
 /* forward: img_nhwc (B,H,W,C), win from dg_roi_windows; out (n,C,P,P) fp32; argmax (n,C,P,P) int32
- * = flat index y*W+x in the feature-map plane (DG_POOL_MAX only, may be NULL).  P must be 7.
+ * = flat index y*W+x in the feature-map plane (DG_POOL_MAX only, may be NULL).  P = 7 on a map of at most 65535 cells
+ * runs the tuned kernel (VGG16 conv5, the reference's call site rcnn/fast_rcnn.py:381); any other P >= 1 or map size runs
+ * the general one (dg_roipool_fwd_any_f32 also takes non-square output sizes).
  * nan_flag: the word dg_nchw_to_nhwc_f32 wrote (0 = no NaN in the map: the kernel skips ATen's "NaN always
  * wins" test), or NULL = unknown (NaN-exact path). */
 int dg_roipool_fwd_f32(const float *img_nhwc, int64_t B, int64_t C, int64_t H, int64_t W,
                        const int32_t *win, int64_t n, int64_t P, int mode, const int32_t *nan_flag,
                        float *out, int32_t *argmax, dg_stream_t s);
+/* slowroipool(output_size) hands output_size -- an int or a (PH, PW) pair -- straight to the adaptive pool
+ * (rcnn/fast_rcnn.py:352-355): out / argmax are (n,C,PH,PW). */
+int dg_roipool_fwd_any_f32(const float *img_nhwc, int64_t B, int64_t C, int64_t H, int64_t W,
+                           const int32_t *win, int64_t n, int64_t PH, int64_t PW, int mode, const int32_t *nan_flag,
+                           float *out, int32_t *argmax, dg_stream_t s);
 /* The same forward with the argmax written as uint16 (H*W <= 65535 is a precondition of the forward anyway): half the
  * index bytes to write here and to read in the backward.  The reference has no argmax tensor (autograd keeps its own
  * indices), so its width is this build's choice; the int32 entry points above stay for callers that want one. */
@@ -150,7 +157,12 @@ size_t dg_roipool_bwd_workspace_bytes(int64_t B, int64_t n);
 int dg_roipool_bwd_f32(const float *grad_out, const int32_t *argmax, const int32_t *win, int64_t n,
                        int64_t B, int64_t C, int64_t H, int64_t W, int64_t P, int mode, float *grad_in,
                        void *ws, size_t ws_bytes, dg_stream_t s);
-/* backward from a uint16 argmax (dg_roipool_fwd_a16_f32); otherwise as dg_roipool_bwd_f32 */
+/* any output size PH x PW and any map size (7 x 7 on planes that fit the LDS accumulator -- H*W <= 32768 in max mode,
+ * 14336 in avg mode -- runs the tuned kernel, everything else global float atomics into a zeroed grad_in) */
+int dg_roipool_bwd_any_f32(const float *grad_out, const int32_t *argmax, const int32_t *win, int64_t n,
+                           int64_t B, int64_t C, int64_t H, int64_t W, int64_t PH, int64_t PW, int mode, float *grad_in,
+                           void *ws, size_t ws_bytes, dg_stream_t s);
+/* backward from a uint16 argmax (dg_roipool_fwd_a16_f32; maps of at most 65535 cells); otherwise as dg_roipool_bwd_f32 */
 int dg_roipool_bwd_a16_f32(const float *grad_out, const uint16_t *argmax16, const int32_t *win, int64_t n,
                            int64_t B, int64_t C, int64_t H, int64_t W, int64_t P, int mode, float *grad_in,
                            void *ws, size_t ws_bytes, dg_stream_t s);

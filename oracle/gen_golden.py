@@ -375,6 +375,53 @@ def gen_roipool():
     np.savez_compressed(os.path.join(OUT, "roipool.npz"), **d)
 
 
+def gen_roipool_sizes():
+    """slowroipool(output_size) for output sizes other than (7,7): the reference passes output_size to the adaptive pool
+    (rcnn/fast_rcnn.py:352-355), so any int or pair is legal.  As written (avg) and with AdaptiveMaxPool2d substituted,
+    forward + autograd gradients, on a small map with crops from 1 cell up to the whole map."""
+    ns = extract_lines("rcnn/fast_rcnn.py", 351, 377, base_ns())
+    Pool = ns["slowroipool"]
+    rng = np.random.default_rng(16)
+    B, C, H, W = 2, 5, 23, 31
+    img = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    img[0, 0, 3:6, 4:9] = 1.5                       # ties inside bins
+    n = 40
+    xy = rng.uniform(0, 0.8, (n, 2)); wh = rng.uniform(0.02, 0.9, (n, 2))
+    rois = np.clip(np.concatenate([xy, xy + wh], 1), 0, 1)
+    rois[0] = [0, 0, 1, 1]
+    rois[1] = [0.5, 0.5, 0.5001, 0.5001]
+    idx = rng.integers(0, B, n).astype(np.int64)
+    d = dict(img=img, rois=rois, idx=idx)
+    x1 = np.floor(rois[:, 0] * W).astype(int); x2 = np.ceil(rois[:, 2] * W).astype(int)
+    y1 = np.floor(rois[:, 1] * H).astype(int); y2_ = np.ceil(rois[:, 3] * H).astype(int)
+    for tag, size in {"s3x5": (3, 5), "s14": 14, "s1": 1, "s2x9": (2, 9)}.items():
+        PH, PW = size if isinstance(size, tuple) else (size, size)
+        gout = rng.standard_normal((n, C, PH, PW)).astype(np.float32)
+        timg = torch.from_numpy(img).requires_grad_(True)
+        m = Pool(size)
+        y = m.foward(timg, rois, idx)
+        y.backward(torch.from_numpy(gout))
+        d[f"{tag}_size"] = np.array([PH, PW]); d[f"{tag}_grad_out"] = gout
+        d[f"{tag}_avg_out"] = y.detach().numpy(); d[f"{tag}_avg_grad_in"] = timg.grad.numpy().copy()
+        timg.grad = None
+        m2 = Pool(size)
+        m2.maxpool = nn.AdaptiveMaxPool2d(size)
+        y2 = m2.foward(timg, rois, idx)
+        y2.backward(torch.from_numpy(gout))
+        d[f"{tag}_max_out"] = y2.detach().numpy(); d[f"{tag}_max_grad_in"] = timg.grad.numpy().copy()
+        arg = np.zeros((n, C, PH, PW), np.int32)
+        pool_i = nn.AdaptiveMaxPool2d(size, return_indices=True)
+        for i in range(n):
+            crop = timg.detach()[idx[i], :, y1[i]:y2_[i], x1[i]:x2[i]].unsqueeze(0)
+            v, ind = pool_i(crop)
+            assert torch.equal(v[0], y2.detach()[i])
+            cw = x2[i] - x1[i]
+            ind = ind[0].numpy()
+            arg[i] = ((ind // cw) + y1[i]) * W + (ind % cw) + x1[i]
+        d[f"{tag}_max_argmax"] = arg
+    np.savez_compressed(os.path.join(OUT, "roipool_sizes.npz"), **d)
+
+
 # ------------------------------------------------------------------ YOLOv2 get_point, R-CNN calcul/decode, do_ss
 def gen_misc():
     ns = extract_defs("yolo/yolo_v2/utils.py", {"get_point"}, base_ns())
@@ -458,7 +505,7 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
     torch.set_num_threads(1)
-    which = sys.argv[1:] or ["iou", "nms", "decode", "roipool", "misc", "cluster", "loss", "encode"]
+    which = sys.argv[1:] or ["iou", "nms", "decode", "roipool", "roipool_sizes", "misc", "cluster", "loss", "encode"]
     for w in which:
         print("generating", w, flush=True)
         globals()["gen_" + w]()

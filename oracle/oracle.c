@@ -229,9 +229,10 @@ int orc_roi_window(const double *roi, int H, int W, int *x1, int *y1, int *x2, i
     return ORC_OK;
 }
 
-int orc_roipool_fwd_f32(const float *img, int64_t B, int64_t C, int H, int W,
-                        const double *rois, const int64_t *roi_idx, int64_t n, int P, int mode,
-                        float *out, int32_t *argmax)
+/* output_size may be an int or a (PH, PW) pair (rcnn/fast_rcnn.py:352-355 hands it to the adaptive pool) */
+int orc_roipool_fwd2_f32(const float *img, int64_t B, int64_t C, int H, int W,
+                         const double *rois, const int64_t *roi_idx, int64_t n, int PH, int PW, int mode,
+                         float *out, int32_t *argmax)
 {
     for (int64_t r = 0; r < n; ++r) {
         int x1, y1, x2, y2;
@@ -242,11 +243,11 @@ int orc_roipool_fwd_f32(const float *img, int64_t B, int64_t C, int H, int W,
         int Lh = y2 - y1, Lw = x2 - x1;
         for (int64_t c = 0; c < C; ++c) {
             const float *plane = img + (b * C + c) * (int64_t)H * W;
-            for (int ph = 0; ph < P; ++ph) {
-                int hs = y1 + bin_start(ph, Lh, P), he = y1 + bin_end(ph, Lh, P);
-                for (int pw = 0; pw < P; ++pw) {
-                    int ws = x1 + bin_start(pw, Lw, P), we = x1 + bin_end(pw, Lw, P);
-                    int64_t o = ((r * C + c) * P + ph) * P + pw;
+            for (int ph = 0; ph < PH; ++ph) {
+                int hs = y1 + bin_start(ph, Lh, PH), he = y1 + bin_end(ph, Lh, PH);
+                for (int pw = 0; pw < PW; ++pw) {
+                    int ws = x1 + bin_start(pw, Lw, PW), we = x1 + bin_end(pw, Lw, PW);
+                    int64_t o = ((r * C + c) * PH + ph) * PW + pw;
                     if (mode == 1) {
                         float best = -INFINITY; int32_t bi = hs * W + ws;
                         for (int y = hs; y < he; ++y)
@@ -269,12 +270,19 @@ int orc_roipool_fwd_f32(const float *img, int64_t B, int64_t C, int H, int W,
     return ORC_OK;
 }
 
+int orc_roipool_fwd_f32(const float *img, int64_t B, int64_t C, int H, int W,
+                        const double *rois, const int64_t *roi_idx, int64_t n, int P, int mode,
+                        float *out, int32_t *argmax)
+{
+    return orc_roipool_fwd2_f32(img, B, C, H, W, rois, roi_idx, n, P, P, mode, out, argmax);
+}
+
 /* ---- R2: backward of R1 (autograd in the reference; no explicit code).
  * max: grad_in[b,c,argmax] += grad_out ; avg: grad_out / kh / kw spread over the bin.
  * Sequential accumulation in RoI order (fp32). grad_in must be zeroed by the caller. */
-int orc_roipool_bwd_f32(const float *grad_out, const int32_t *argmax, int64_t B, int64_t C, int H, int W,
-                        const double *rois, const int64_t *roi_idx, int64_t n, int P, int mode,
-                        float *grad_in)
+int orc_roipool_bwd2_f32(const float *grad_out, const int32_t *argmax, int64_t B, int64_t C, int H, int W,
+                         const double *rois, const int64_t *roi_idx, int64_t n, int PH, int PW, int mode,
+                         float *grad_in)
 {
     for (int64_t r = 0; r < n; ++r) {
         int x1, y1, x2, y2;
@@ -284,14 +292,14 @@ int orc_roipool_bwd_f32(const float *grad_out, const int32_t *argmax, int64_t B,
         int Lh = y2 - y1, Lw = x2 - x1;
         for (int64_t c = 0; c < C; ++c) {
             float *plane = grad_in + (b * C + c) * (int64_t)H * W;
-            for (int ph = 0; ph < P; ++ph)
-                for (int pw = 0; pw < P; ++pw) {
-                    int64_t o = ((r * C + c) * P + ph) * P + pw;
+            for (int ph = 0; ph < PH; ++ph)
+                for (int pw = 0; pw < PW; ++pw) {
+                    int64_t o = ((r * C + c) * PH + ph) * PW + pw;
                     if (mode == 1) {
                         plane[argmax[o]] += grad_out[o];
                     } else {
-                        int hs = y1 + bin_start(ph, Lh, P), he = y1 + bin_end(ph, Lh, P);
-                        int ws = x1 + bin_start(pw, Lw, P), we = x1 + bin_end(pw, Lw, P);
+                        int hs = y1 + bin_start(ph, Lh, PH), he = y1 + bin_end(ph, Lh, PH);
+                        int ws = x1 + bin_start(pw, Lw, PW), we = x1 + bin_end(pw, Lw, PW);
                         float g = grad_out[o] / (float)(he - hs) / (float)(we - ws);
                         for (int y = hs; y < he; ++y)
                             for (int x = ws; x < we; ++x) plane[y * W + x] += g;
@@ -300,6 +308,13 @@ int orc_roipool_bwd_f32(const float *grad_out, const int32_t *argmax, int64_t B,
         }
     }
     return ORC_OK;
+}
+
+int orc_roipool_bwd_f32(const float *grad_out, const int32_t *argmax, int64_t B, int64_t C, int H, int W,
+                        const double *rois, const int64_t *roi_idx, int64_t n, int P, int mode,
+                        float *grad_in)
+{
+    return orc_roipool_bwd2_f32(grad_out, argmax, B, C, H, W, rois, roi_idx, n, P, P, mode, grad_in);
 }
 
 /* ---- D3: yolo/yolo_v2/utils.py:228-234 get_point (encoder) and its inverse ---------

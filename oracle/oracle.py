@@ -109,17 +109,22 @@ def yolo1_decode(output, target=None, conf_threshold=0.2, prob_threshold=0.1):
 
 
 # ------------------------------------------------------------------ RoI pool
+def _pool_size(P):
+    return (int(P[0]), int(P[1])) if isinstance(P, (tuple, list)) else (int(P), int(P))
+
+
 def roipool_fwd(img, rois, roi_idx, P=7, mode="max"):
     img = _f32(img)
     B, Cc, H, W = img.shape
+    PH, PW = _pool_size(P)
     rois = np.ascontiguousarray(rois, np.float64).reshape(-1, 4)
     idx = np.ascontiguousarray(roi_idx, np.int64)
     n = rois.shape[0]
-    out = np.empty((n, Cc, P, P), np.float32)
-    arg = np.empty((n, Cc, P, P), np.int32) if mode == "max" else None
-    st = lib().orc_roipool_fwd_f32(_p(img), C.c_int64(B), C.c_int64(Cc), C.c_int(H), C.c_int(W), _p(rois), _p(idx),
-                                   C.c_int64(n), C.c_int(P), C.c_int(1 if mode == "max" else 0), _p(out),
-                                   _p(arg) if arg is not None else None)
+    out = np.empty((n, Cc, PH, PW), np.float32)
+    arg = np.empty((n, Cc, PH, PW), np.int32) if mode == "max" else None
+    st = lib().orc_roipool_fwd2_f32(_p(img), C.c_int64(B), C.c_int64(Cc), C.c_int(H), C.c_int(W), _p(rois), _p(idx),
+                                    C.c_int64(n), C.c_int(PH), C.c_int(PW), C.c_int(1 if mode == "max" else 0), _p(out),
+                                    _p(arg) if arg is not None else None)
     if st == EEMPTYROI:
         raise RuntimeError("empty RoI crop")
     assert st == OK, st
@@ -128,14 +133,15 @@ def roipool_fwd(img, rois, roi_idx, P=7, mode="max"):
 
 def roipool_bwd(grad_out, argmax, img_shape, rois, roi_idx, P=7, mode="max"):
     B, Cc, H, W = img_shape
+    PH, PW = _pool_size(P)
     g = _f32(grad_out)
     rois = np.ascontiguousarray(rois, np.float64).reshape(-1, 4)
     idx = np.ascontiguousarray(roi_idx, np.int64)
     gin = np.zeros((B, Cc, H, W), np.float32)
     a = np.ascontiguousarray(argmax, np.int32) if argmax is not None else None
-    st = lib().orc_roipool_bwd_f32(_p(g), _p(a) if a is not None else None, C.c_int64(B), C.c_int64(Cc), C.c_int(H),
-                                   C.c_int(W), _p(rois), _p(idx), C.c_int64(rois.shape[0]), C.c_int(P),
-                                   C.c_int(1 if mode == "max" else 0), _p(gin))
+    st = lib().orc_roipool_bwd2_f32(_p(g), _p(a) if a is not None else None, C.c_int64(B), C.c_int64(Cc), C.c_int(H),
+                                    C.c_int(W), _p(rois), _p(idx), C.c_int64(rois.shape[0]), C.c_int(PH), C.c_int(PW),
+                                    C.c_int(1 if mode == "max" else 0), _p(gin))
     assert st == OK, st
     return gin
 

@@ -37,8 +37,10 @@ def test_argument_validation_without_gpu():
     assert lib.dg_iou_elementwise_f32(None, None, -1, 1e-7, None, None) == _abi.EINVAL
     assert "n < 0" in _abi.last_error()
     assert lib.dg_iou_pairwise_f32(None, 4, None, 4, 1e-7, None, None) == _abi.EINVAL
-    assert lib.dg_roipool_fwd_f32(None, 1, 8, 4, 4, None, 1, 5, 1, None, None, None, None) == _abi.EINVAL
-    assert "output_size 7" in _abi.last_error()
+    assert lib.dg_roipool_fwd_f32(None, 1, 8, 4, 4, None, 1, 0, 1, None, None, None, None) == _abi.EINVAL
+    assert "output size" in _abi.last_error()
+    assert lib.dg_roipool_fwd_f32(None, 1, 8, 4, 4, None, 1, 5, 1, None, None, None, None) == _abi.EINVAL      # null pointers
+    assert lib.dg_roipool_fwd_a16_f32(None, 1, 8, 400, 400, None, 0, 7, 1, None, None, None, None) == _abi.OK   # n == 0
     assert lib.dg_kmeans_iou_step(None, 10, None, 17, None, None, None, 0, None) == _abi.EINVAL
     with pytest.raises(ValueError):
         _abi.check(_abi.EINVAL)

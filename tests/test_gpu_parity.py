@@ -552,6 +552,59 @@ def test_roipool_avg_backward_vs_oracle(va, oracle, B, C, H, W, reps):
     np.testing.assert_allclose(out.cpu().numpy(), wout, rtol=1e-5, atol=1e-5)
 
 
+def test_roipool_other_output_sizes_golden(va, golden):
+    """slowroipool(output_size) for sizes other than (7,7), through the drop-in class with autograd, against vectors
+    generated from the reference class (rcnn/fast_rcnn.py:351-377) and torch's autograd."""
+    from vision_amd import fast_rcnn
+    g = golden("roipool_sizes")
+    for tag in ("s3x5", "s14", "s1", "s2x9"):
+        P = tuple(int(v) for v in g[f"{tag}_size"])
+        size = P if P[0] != P[1] else P[0]
+        for mode in ("max", "avg"):
+            x = torch.from_numpy(g["img"]).cuda().requires_grad_(True)
+            m = fast_rcnn.slowroipool(size, mode=mode)
+            y = m.foward(x, g["rois"], g["idx"])
+            assert tuple(y.shape) == g[f"{tag}_{mode}_out"].shape
+            if mode == "max":
+                assert np.array_equal(y.detach().cpu().numpy(), g[f"{tag}_max_out"]), tag
+            else:
+                np.testing.assert_allclose(y.detach().cpu().numpy(), g[f"{tag}_avg_out"], rtol=1e-6, atol=1e-6)
+            y.backward(torch.from_numpy(g[f"{tag}_grad_out"]).cuda())
+            np.testing.assert_allclose(x.grad.cpu().numpy(), g[f"{tag}_{mode}_grad_in"], rtol=1e-5, atol=1e-5)
+        m = fast_rcnn.slowroipool(size, mode="max")
+        m.foward(torch.from_numpy(g["img"]).cuda(), g["rois"], g["idx"])
+        assert np.array_equal(m.argmax.cpu().numpy(), g[f"{tag}_max_argmax"]), tag
+
+
+@pytest.mark.parametrize("H,W,P,mode", [(300, 260, 7, "max"), (300, 260, 7, "avg"), (150, 200, 7, "max"), (130, 120, 7, "avg"),
+                                        (300, 260, (4, 6), "max"), (38, 50, 5, "max")])
+def test_roipool_large_maps_and_sizes_vs_oracle(va, oracle, H, W, P, mode):
+    """maps beyond the tuned kernels' limits (forward: 65535 cells; backward plane in LDS: 32768 cells in max mode, 14336 in
+    avg mode) and other output sizes, forward and backward against the oracle."""
+    from vision_amd import ops
+    rng = np.random.default_rng(H * W)
+    B, C = 2, 6
+    img = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    n = 60
+    xy = rng.uniform(0, 0.7, (n, 2)); wh = rng.uniform(0.01, 0.3, (n, 2))
+    rois = np.concatenate([xy, xy + wh], 1)
+    rois[0] = [0, 0, 1, 1]
+    idx = rng.integers(0, B, n).astype(np.int64)
+    dev = torch.device("cuda", 0)
+    win, st = ops.roi_windows(rois, idx, B, H, W, dev)
+    assert int(st.item()) == 0
+    out, arg = ops.roipool_forward(torch.from_numpy(img).to(dev), win, mode, P=P)
+    wout, warg = oracle.roipool_fwd(img, rois, idx, P, mode)
+    if mode == "max":
+        assert np.array_equal(out.cpu().numpy(), wout) and np.array_equal(arg.cpu().numpy(), warg)
+    else:
+        np.testing.assert_allclose(out.cpu().numpy(), wout, rtol=1e-5, atol=1e-5)
+    gout = rng.standard_normal(wout.shape).astype(np.float32)
+    gin = ops.roipool_backward(torch.from_numpy(gout).to(dev), arg, win, img.shape, mode, P=P).cpu().numpy()
+    want = oracle.roipool_bwd(gout, warg, img.shape, rois, idx, P, mode)
+    np.testing.assert_allclose(gin, want, rtol=1e-4, atol=1e-4)
+
+
 def test_roipool_odd_channels_and_batch(va, oracle):
     from vision_amd import ops
     rng = np.random.default_rng(2)

@@ -102,6 +102,22 @@ def test_roipool(golden, oracle):
         oracle.roipool_fwd(g["img"], g["empty_rois"], g["idx"][:2])
 
 
+def test_roipool_other_output_sizes(golden, oracle):
+    """slowroipool(output_size) with sizes other than (7,7) -- the reference's class as written (avg) and with
+    AdaptiveMaxPool2d substituted, values, argmax and autograd gradients generated from the reference."""
+    g = golden("roipool_sizes")
+    for tag in ("s3x5", "s14", "s1", "s2x9"):
+        P = tuple(int(v) for v in g[f"{tag}_size"])
+        out, arg = oracle.roipool_fwd(g["img"], g["rois"], g["idx"], P, "max")
+        assert np.array_equal(out, g[f"{tag}_max_out"]) and np.array_equal(arg, g[f"{tag}_max_argmax"]), tag
+        avg, _ = oracle.roipool_fwd(g["img"], g["rois"], g["idx"], P, "avg")
+        np.testing.assert_allclose(avg, g[f"{tag}_avg_out"], rtol=1e-6, atol=1e-6)
+        gin = oracle.roipool_bwd(g[f"{tag}_grad_out"], arg, g["img"].shape, g["rois"], g["idx"], P, "max")
+        np.testing.assert_allclose(gin, g[f"{tag}_max_grad_in"], rtol=1e-5, atol=1e-5)
+        gin = oracle.roipool_bwd(g[f"{tag}_grad_out"], None, g["img"].shape, g["rois"], g["idx"], P, "avg")
+        np.testing.assert_allclose(gin, g[f"{tag}_avg_grad_in"], rtol=1e-5, atol=1e-5)
+
+
 def test_yolo2_get_point(golden, oracle):
     g = golden("yolo2_get_point")
     pts, enc = oracle.yolo2_get_point(g["bbox"])

@@ -43,6 +43,8 @@ SIGNATURES = {
     "dg_roi_windows": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "dg_nchw_to_nhwc_f32": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _vp, _vp, _vp]),
     "dg_roipool_fwd_f32": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, C.c_int, _vp, _vp, _vp, _vp]),
+    "dg_roipool_fwd_any_f32": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, C.c_int, _vp, _vp, _vp, _vp]),
+    "dg_roipool_bwd_any_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, _i64, C.c_int, _vp, _vp, _sz, _vp]),
     "dg_roipool_fwd_a16_f32": (C.c_int, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, C.c_int, _vp, _vp, _vp, _vp]),
     "dg_roipool_bwd_workspace_bytes": (_sz, [_i64, _i64]),
     "dg_roipool_bwd_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i64, _i64, _i64, _i64, C.c_int, _vp, _vp, _sz, _vp]),

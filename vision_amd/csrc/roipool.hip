@@ -1021,15 +1021,25 @@ extern "C" int dg_nchw_to_nhwc_f32(const float *src, int64_t B, int64_t C, int64
     return DG_OK;
 }
 
-static int roipool_fwd(const float *img_nhwc, int64_t B, int64_t C, int64_t H, int64_t W, const int32_t *win, int64_t n, int64_t P,
-                       int mode, const int32_t *nan_flag, float *out, int32_t *argmax, uint16_t *argmax16, dg_stream_t s)
+// roipool_generic.hip: any output size, any map size
+int dg_roipool_fwd_generic(const float *img_nhwc, int64_t B, int64_t C, int64_t H, int64_t W, const int32_t *win, int64_t n,
+                           int64_t PH, int64_t PW, int mode, float *out, int32_t *argmax, hipStream_t st);
+int dg_roipool_bwd_generic(const float *grad_out, const void *argmax, bool a16, const int32_t *win, int64_t n, int64_t B, int64_t C,
+                           int64_t H, int64_t W, int64_t PH, int64_t PW, int mode, float *grad_in, hipStream_t st);
+
+static int roipool_fwd(const float *img_nhwc, int64_t B, int64_t C, int64_t H, int64_t W, const int32_t *win, int64_t n, int64_t PH,
+                       int64_t PW, int mode, const int32_t *nan_flag, float *out, int32_t *argmax, uint16_t *argmax16, dg_stream_t s)
 {
     DG_REQUIRE(n >= 0 && B > 0 && C > 0 && H > 0 && W > 0, "roipool_fwd: bad shape");
-    DG_REQUIRE(P == RP, "roipool_fwd: only output_size 7 is built (got %lld)", (long long)P);
+    DG_REQUIRE(PH >= 1 && PW >= 1 && PH * PW <= (1 << 20), "roipool_fwd: output size must be >= 1 x 1 (got %lld x %lld)", (long long)PH, (long long)PW);
     DG_REQUIRE(mode == DG_POOL_MAX || mode == DG_POOL_AVG, "roipool_fwd: bad mode");
-    DG_REQUIRE(H * W <= 65535, "roipool_fwd: H*W > 65535 unsupported (16-bit staged argmax)");
     if (n == 0) return DG_OK;
     DG_REQUIRE(img_nhwc && win && out, "roipool_fwd: null pointer");
+    if (PH != RP || PW != RP || H * W > 65535) {
+        // the general kernel: output sizes other than 7 x 7, maps beyond the 16-bit staged index
+        DG_REQUIRE(!argmax16, "roipool_fwd: the uint16 argmax exists for 7 x 7 outputs on maps of at most 65535 cells");
+        return dg_roipool_fwd_generic(img_nhwc, B, C, H, W, win, n, PH, PW, mode, out, argmax, (hipStream_t)s);
+    }
     DG_REQUIRE((((uintptr_t)argmax16) & 1) == 0, "roipool_fwd: misaligned argmax16");
     int vec_ok = ((C % 4 == 0) && ((((uintptr_t)out) & 15) == 0) && (!argmax || (((uintptr_t)argmax) & 15) == 0)) ? 1 : 0;
     if (argmax16 && C % 8 == 0 && (((uintptr_t)argmax16) & 15) == 0) vec_ok |= 2;
@@ -1052,14 +1062,21 @@ extern "C" int dg_roipool_fwd_f32(const float *img_nhwc, int64_t B, int64_t C, i
                                   const int32_t *win, int64_t n, int64_t P, int mode, const int32_t *nan_flag,
                                   float *out, int32_t *argmax, dg_stream_t s)
 {
-    return roipool_fwd(img_nhwc, B, C, H, W, win, n, P, mode, nan_flag, out, argmax, nullptr, s);
+    return roipool_fwd(img_nhwc, B, C, H, W, win, n, P, P, mode, nan_flag, out, argmax, nullptr, s);
+}
+
+extern "C" int dg_roipool_fwd_any_f32(const float *img_nhwc, int64_t B, int64_t C, int64_t H, int64_t W,
+                                      const int32_t *win, int64_t n, int64_t PH, int64_t PW, int mode, const int32_t *nan_flag,
+                                      float *out, int32_t *argmax, dg_stream_t s)
+{
+    return roipool_fwd(img_nhwc, B, C, H, W, win, n, PH, PW, mode, nan_flag, out, argmax, nullptr, s);
 }
 
 extern "C" int dg_roipool_fwd_a16_f32(const float *img_nhwc, int64_t B, int64_t C, int64_t H, int64_t W,
                                       const int32_t *win, int64_t n, int64_t P, int mode, const int32_t *nan_flag,
                                       float *out, uint16_t *argmax16, dg_stream_t s)
 {
-    return roipool_fwd(img_nhwc, B, C, H, W, win, n, P, mode, nan_flag, out, nullptr, argmax16, s);
+    return roipool_fwd(img_nhwc, B, C, H, W, win, n, P, P, mode, nan_flag, out, nullptr, argmax16, s);
 }
 
 struct BwdWs { int32_t *cnt, *off, *cursor, *list; size_t total; };
@@ -1084,11 +1101,11 @@ extern "C" size_t dg_roipool_bwd_workspace_bytes(int64_t B, int64_t n)
 }
 
 static int roipool_bwd(const float *grad_out, const void *argmax, bool a16, const int32_t *win, int64_t n,
-                       int64_t B, int64_t C, int64_t H, int64_t W, int64_t P, int mode, float *grad_in,
+                       int64_t B, int64_t C, int64_t H, int64_t W, int64_t PH, int64_t PW, int mode, float *grad_in,
                        void *ws, size_t ws_bytes, dg_stream_t s)
 {
     DG_REQUIRE(n >= 0 && B > 0 && C > 0 && H > 0 && W > 0, "roipool_bwd: bad shape");
-    DG_REQUIRE(P == RP, "roipool_bwd: only output_size 7 is built");
+    DG_REQUIRE(PH >= 1 && PW >= 1, "roipool_bwd: output size must be >= 1 x 1");
     DG_REQUIRE(mode == DG_POOL_MAX || mode == DG_POOL_AVG, "roipool_bwd: bad mode");
     DG_REQUIRE(grad_in && ws, "roipool_bwd: null pointer");
     DG_REQUIRE(n == 0 || (grad_out && win), "roipool_bwd: null pointer");
@@ -1097,8 +1114,16 @@ static int roipool_bwd(const float *grad_out, const void *argmax, bool a16, cons
     BwdWs w = bwd_layout(B, n, ws);
     if (ws_bytes < w.total) { dg_set_error("roipool_bwd: workspace %zu < %zu bytes", ws_bytes, w.total); return DG_ENOMEM; }
     const int64_t HW = H * W;
-    DG_REQUIRE(HW * 4 <= 64 * 1024, "roipool_bwd: feature plane H*W*4 > 64 KiB does not fit the LDS accumulator");
     hipStream_t st = (hipStream_t)s;
+    // The tuned kernel keeps whole planes of grad_in in LDS: 7 x 7 outputs, one plane within 128 KiB (max mode; H*W <= 32768)
+    // or a [pixel][4] plane within 64 KiB beside the 8 KiB of shares (avg mode, as before).  Everything else -- other output
+    // sizes, larger maps -- goes through the general kernel (global float atomics into a zeroed grad_in).
+    const int64_t plane_limit = (mode == DG_POOL_MAX ? 128 : 56) * 1024;
+    if (PH != RP || PW != RP || HW * 4 > plane_limit || (a16 && HW > 65535)) {
+        DG_REQUIRE(!(a16 && HW > 65535), "roipool_bwd: a uint16 argmax cannot index a map of more than 65535 cells");
+        if (n == 0) return hipMemsetAsync(grad_in, 0, (size_t)B * C * HW * 4, st) == hipSuccess ? DG_OK : DG_EHIP;
+        return dg_roipool_bwd_generic(grad_out, argmax, a16, win, n, B, C, H, W, PH, PW, mode, grad_in, st);
+    }
     if (hipMemsetAsync(w.cnt, 0, (size_t)B * 4, st) != hipSuccess) { dg_set_error("roipool_bwd: memset failed"); return DG_EHIP; }
     if (n > 0) hipLaunchKernelGGL(k_roi_count, dim3((unsigned)dg_cdiv(n, 256)), dim3(256), 0, st, win, n, w.cnt);
     hipLaunchKernelGGL(k_roi_scan, dim3(1), dim3(1024), 0, st, w.cnt, (int)B, w.off, w.cursor);
@@ -1139,12 +1164,19 @@ extern "C" int dg_roipool_bwd_f32(const float *grad_out, const int32_t *argmax, 
                                   int64_t B, int64_t C, int64_t H, int64_t W, int64_t P, int mode, float *grad_in,
                                   void *ws, size_t ws_bytes, dg_stream_t s)
 {
-    return roipool_bwd(grad_out, argmax, false, win, n, B, C, H, W, P, mode, grad_in, ws, ws_bytes, s);
+    return roipool_bwd(grad_out, argmax, false, win, n, B, C, H, W, P, P, mode, grad_in, ws, ws_bytes, s);
+}
+
+extern "C" int dg_roipool_bwd_any_f32(const float *grad_out, const int32_t *argmax, const int32_t *win, int64_t n,
+                                      int64_t B, int64_t C, int64_t H, int64_t W, int64_t PH, int64_t PW, int mode, float *grad_in,
+                                      void *ws, size_t ws_bytes, dg_stream_t s)
+{
+    return roipool_bwd(grad_out, argmax, false, win, n, B, C, H, W, PH, PW, mode, grad_in, ws, ws_bytes, s);
 }
 
 extern "C" int dg_roipool_bwd_a16_f32(const float *grad_out, const uint16_t *argmax16, const int32_t *win, int64_t n,
                                       int64_t B, int64_t C, int64_t H, int64_t W, int64_t P, int mode, float *grad_in,
                                       void *ws, size_t ws_bytes, dg_stream_t s)
 {
-    return roipool_bwd(grad_out, argmax16, true, win, n, B, C, H, W, P, mode, grad_in, ws, ws_bytes, s);
+    return roipool_bwd(grad_out, argmax16, true, win, n, B, C, H, W, P, P, mode, grad_in, ws, ws_bytes, s);
 }

@@ -17,9 +17,11 @@ from . import ops
 
 class _RoIPoolFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, img, win, mode):
-        out, argmax = ops.roipool_forward(img, win, mode, argmax_dtype=torch.int16)   # uint16 indices: half the bytes
-        ctx.mode, ctx.img_shape = mode, tuple(img.shape)
+    def forward(ctx, img, win, mode, size):
+        small = tuple(size) == (7, 7) and img.shape[2] * img.shape[3] <= 65535
+        out, argmax = ops.roipool_forward(img, win, mode, P=size,
+                                          argmax_dtype=torch.int16 if small else torch.int32)   # uint16 indices: half the bytes
+        ctx.mode, ctx.img_shape, ctx.size = mode, tuple(img.shape), tuple(size)
         ctx.save_for_backward(win, argmax if argmax is not None else win)
         ctx.argmax = argmax
         return out
@@ -27,21 +29,21 @@ class _RoIPoolFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_out):
         win, arg = ctx.saved_tensors
-        g = ops.roipool_backward(grad_out.contiguous(), arg if ctx.mode == "max" else None, win, ctx.img_shape, ctx.mode)
-        return g, None, None
+        g = ops.roipool_backward(grad_out.contiguous(), arg if ctx.mode == "max" else None, win, ctx.img_shape, ctx.mode, P=ctx.size)
+        return g, None, None, None
 
 
 class slowroipool(torch.nn.Module):
     def __init__(self, output_size, mode="avg"):
         super().__init__()
-        size = tuple(output_size) if isinstance(output_size, (tuple, list)) else (output_size, output_size)
-        if size != (7, 7):
-            raise ValueError("slowroipool: only output_size (7,7) is built")
+        size = tuple(int(v) for v in output_size) if isinstance(output_size, (tuple, list)) else (int(output_size), int(output_size))
+        if len(size) != 2 or min(size) < 1:
+            raise ValueError("slowroipool: output_size must be a positive int or a pair of them")
         if mode not in ("max", "avg"):
             raise ValueError("mode must be 'max' or 'avg'")
         self.size = size
         self.mode = mode
-        self.argmax = None            # (n,C,7,7) int32 of the last max-mode forward (flat y*W+x in the map)
+        self.argmax = None            # (n,C,PH,PW) int32 of the last max-mode forward (flat y*W+x in the map)
 
     def foward(self, img, roi_ary, roi_idx):          # sic: the reference's spelling (:357)
         was_cpu = not img.is_cuda
@@ -57,9 +59,9 @@ class slowroipool(torch.nn.Module):
         if st & 2:
             raise IndexError("slowroipool: roi_idx out of range")
         if x.requires_grad:
-            out = _RoIPoolFn.apply(x, win, self.mode)
+            out = _RoIPoolFn.apply(x, win, self.mode, self.size)
         else:
-            out, self.argmax = ops.roipool_forward(x, win, self.mode)
+            out, self.argmax = ops.roipool_forward(x, win, self.mode, P=self.size)
         return out.cpu() if was_cpu else out
 
     forward = foward

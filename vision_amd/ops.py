@@ -224,26 +224,40 @@ def to_nhwc(img, out=None, nan_flag=None):
     return out, nan_flag
 
 
+def _pool_size(P):
+    if isinstance(P, (tuple, list)):
+        if len(P) != 2:
+            raise ValueError("output_size must be an int or a (PH, PW) pair")
+        return int(P[0]), int(P[1])
+    return int(P), int(P)
+
+
 def roipool_forward(img, win, mode="max", P=7, out=None, argmax=None, nhwc=None, nan_flag=None, argmax_dtype=torch.int32):
-    """argmax: int32 (default) or, with argmax_dtype=torch.int16 / an int16 tensor passed in, the uint16 bit pattern of the
-    same index (widen with `argmax_i32`): half the index bytes in the forward and the backward."""
+    """P: output size, an int or (PH, PW) (rcnn/fast_rcnn.py:352-355 passes it to the adaptive pool).
+    argmax: int32 (default) or, with argmax_dtype=torch.int16 / an int16 tensor passed in, the uint16 bit pattern of the
+    same index (widen with `argmax_i32`): half the index bytes in the forward and the backward (7 x 7, H*W <= 65535 only)."""
     dev = img.device
     B, C_, H, W = img.shape
+    PH, PW = _pool_size(P)
     n = win.shape[0]
     if nhwc is None:
         nhwc, nan_flag = to_nhwc(img)
     m = _abi.POOL_MAX if mode == "max" else _abi.POOL_AVG
     if out is None:
-        out = torch.empty((n, C_, P, P), dtype=torch.float32, device=dev)
+        out = torch.empty((n, C_, PH, PW), dtype=torch.float32, device=dev)
     if m == _abi.POOL_MAX and argmax is None:
-        argmax = torch.empty((n, C_, P, P), dtype=argmax_dtype, device=dev)
+        argmax = torch.empty((n, C_, PH, PW), dtype=argmax_dtype, device=dev)
     a16 = m == _abi.POOL_MAX and argmax.dtype == torch.int16
     if m == _abi.POOL_MAX and argmax.dtype not in (torch.int32, torch.int16):
         raise ValueError("roipool_forward: argmax must be int32 or int16 (uint16 bit pattern)")
-    fn = load().dg_roipool_fwd_a16_f32 if a16 else load().dg_roipool_fwd_f32
     with torch.cuda.device(dev):
-        check(fn(ptr(nhwc), B, C_, H, W, ptr(win), n, P, m, ptr(nan_flag), ptr(out),
-                 ptr(argmax) if m == _abi.POOL_MAX else None, stream_ptr(dev)))
+        if a16:
+            if (PH, PW) != (7, 7):
+                raise ValueError("roipool_forward: the uint16 argmax exists for 7 x 7 outputs only")
+            check(load().dg_roipool_fwd_a16_f32(ptr(nhwc), B, C_, H, W, ptr(win), n, 7, m, ptr(nan_flag), ptr(out), ptr(argmax), stream_ptr(dev)))
+        else:
+            check(load().dg_roipool_fwd_any_f32(ptr(nhwc), B, C_, H, W, ptr(win), n, PH, PW, m, ptr(nan_flag), ptr(out),
+                                                ptr(argmax) if m == _abi.POOL_MAX else None, stream_ptr(dev)))
     return out, (argmax if m == _abi.POOL_MAX else None)
 
 
@@ -255,6 +269,7 @@ def argmax_i32(argmax):
 def roipool_backward(grad_out, argmax, win, img_shape, mode="max", P=7, grad_in=None):
     dev = grad_out.device
     B, C_, H, W = img_shape
+    PH, PW = _pool_size(P)
     n = win.shape[0]
     g = grad_out.contiguous()
     if grad_in is None:
@@ -262,9 +277,12 @@ def roipool_backward(grad_out, argmax, win, img_shape, mode="max", P=7, grad_in=
     nbytes = load().dg_roipool_bwd_workspace_bytes(B, n)
     ws = workspace(dev, nbytes)
     m = _abi.POOL_MAX if mode == "max" else _abi.POOL_AVG
-    fn = load().dg_roipool_bwd_a16_f32 if (argmax is not None and argmax.dtype == torch.int16) else load().dg_roipool_bwd_f32
     with torch.cuda.device(dev):
-        check(fn(ptr(g), ptr(argmax), ptr(win), n, B, C_, H, W, P, m, ptr(grad_in), ptr(ws), nbytes, stream_ptr(dev)))
+        if argmax is not None and argmax.dtype == torch.int16:
+            check(load().dg_roipool_bwd_a16_f32(ptr(g), ptr(argmax), ptr(win), n, B, C_, H, W, PH, m, ptr(grad_in), ptr(ws), nbytes, stream_ptr(dev)))
+        else:
+            check(load().dg_roipool_bwd_any_f32(ptr(g), ptr(argmax), ptr(win), n, B, C_, H, W, PH, PW, m, ptr(grad_in), ptr(ws), nbytes,
+                                                stream_ptr(dev)))
     return grad_in
 
 
