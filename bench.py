@@ -358,18 +358,18 @@ def extra_kmeans(d, n_total=10_000_000, iters=30):
     km = cluster.kmean(5, 42, reduce_device="cpu" if d.rehearse else None)   # rehearsal: gloo reduces host tensors
     km.fit(shard, init_centers=init, fixed_iters=iters)     # warm-up (RCCL channels, graph capture); leaves the device state
     sec = min(Dist.timed(d, lambda: km._run_iters(0, iters), 1, 0) for _ in range(5))   # the Lloyd iterations proper
-    # kernel-only rate of the step on this shard
-    be = km._backend
-    ms = ev_median(be.step, 100, 20)
+    # device time of one iteration on this rank's shard (HIP events around the same 30 iterations: no host sync in it)
+    ms = min(ev_time(lambda: km._run_iters(0, iters), 3, 1) for _ in range(3)) / iters
     r = {"iters_per_s": iters / sec, "ms_per_iter": sec / iters * 1e3, "boxes_total": n_total, "ranks": d.world,
          "sharded_loop": km.graph_state if d.world > 1 else "single device: dg_kmeans_iou_run",
-         "step_kernel_ms_per_shard": ms, "step_hbm_frac": (12.0 * per) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-         "step_valu_frac": valu_frac("k_kmeans_step", per, ms),
+         "device_ms_per_iter_this_shard": ms, "iter_hbm_frac": (12.0 * per) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+         "iter_valu_frac": valu_frac("k_kmeans_step", per, ms),
          "centers": km.cluster_centers_.round(6).tolist(),
          "note": "config 4, strong scaling: 10M boxes sharded; per iteration ONE launch (the centroid update is the prologue of "
                  "the next step) + ONE 17 x int64 all-reduce, the 30 iterations replayed as one HIP graph when capture succeeds; "
                  "timed: best of 5 runs of 30 iterations, device-resident; the inertia sum is formed by the last iteration of a "
-                 "run only, on one rank and on many alike; step_kernel = the plain step with the inertia, median of 100"}
+                 "run only, on one rank and on many alike; device_ms_per_iter = HIP-event time of the same 30 iterations / 30 "
+                 "(k_kmeans_step is VALU-bound: iter_valu_frac = SQ_INSTS_VALU x 64 / time over the chip's 7.86e13 lane-ops/s)"}
     if d.world == 1 and not d.rehearse:
         # what the sharded loop costs per iteration on a 1/8 shard (1.25 M boxes), all-reduce included, on this one GPU:
         # a single-rank RCCL group runs the same launch + all-reduce sequence the 8-GPU job runs on every rank
@@ -383,7 +383,11 @@ def extra_kmeans(d, n_total=10_000_000, iters=30):
                 s8 = min(Dist.timed(d, lambda: k8._run_iters(0, iters), 1, 0) for _ in range(5))
                 r["shard_1p25M_loop_graph" if mode == "1" else "shard_1p25M_loop_eager"] = {
                     "us_per_iter": s8 / iters * 1e6, "state": k8.graph_state}
-            r["shard_1p25M_step_kernel_us"] = ev_median(k8._backend.step, 100, 20) * 1e3
+            os.environ["DG_KMEANS_GRAPH"] = "1"
+            k1 = cluster.kmean(5, 42)                 # the same shard on the single-device loop: kernel time without a collective
+            k1.sharded = False
+            k1.fit(sub, init_centers=init, fixed_iters=iters)
+            r["shard_1p25M_device_us_per_iter_no_collective"] = min(ev_time(lambda: k1._run_iters(0, iters), 3, 1) for _ in range(3)) / iters * 1e3
             os.environ.pop("DG_KMEANS_GRAPH", None)
             dist.destroy_process_group()
         except Exception as e:  # noqa: BLE001
