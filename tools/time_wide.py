@@ -21,3 +21,15 @@ for name, (lo, hi) in {"w 1..16": (0.02, 0.30), "w 17..24": (0.34, 0.46), "w 25.
     ms = a.elapsed_time(b) / 5
     lw = (win[:, 2] - win[:, 0]).float()
     print(f"{name}: widths {int(lw.min())}..{int(lw.max())}  {ms:.3f} ms  {images * n / ms / 1e3:.2f} M RoIs/s", flush=True)
+# the unbounded proposal mix of bench.py's config3_wide_rois (w,h ~ U(0.1,0.9))
+from tools import workloads as wl
+rois = torch.from_numpy(np.concatenate([wl.frcnn_rois_wide(i, n) for i in range(images)])).to(dev)
+idx = torch.arange(images, device=dev).repeat_interleave(n)
+win, st = ops.roi_windows(rois, idx, images, 38, 50, dev)
+out, arg = ops.roipool_forward(img, win, "max", nhwc=nhwc, nan_flag=nanf)
+a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+torch.cuda.synchronize(); a.record()
+for _ in range(5): ops.roipool_forward(img, win, "max", out=out, argmax=arg, nhwc=nhwc, nan_flag=nanf)
+b.record(); torch.cuda.synchronize()
+ms = a.elapsed_time(b) / 5
+print(f"mix U(0.1,0.9): {ms:.3f} ms  {images * n / ms / 1e3:.2f} M RoIs/s", flush=True)

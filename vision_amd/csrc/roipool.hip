@@ -16,6 +16,12 @@
 #include <stdlib.h>
 
 #define RP 7
+#ifndef DG_FWD_STAGED_MAXW
+#define DG_FWD_STAGED_MAXW 24
+#endif
+#ifndef DG_FWD_WIDE
+#define DG_FWD_WIDE 1
+#endif
 #ifndef DG_BWD_XCD_REMAP
 #define DG_BWD_XCD_REMAP 1
 #endif
@@ -426,6 +432,80 @@ __device__ __forceinline__ void direct_max_bin(const float *__restrict__ base, i
     }
 }
 
+// Wide crops (more than 24 cells wide, or strips taller than the LDS ring holds): one-pass exact argmax straight from the
+// map with NO per-cell address arithmetic.  All bin geometry is wave-uniform, so per task each lane keeps 7 x XW byte
+// offsets (column of position j of bin i, clamped to the bin, + this lane's channel) and every load is
+// `global_load_dword v, voff[i][j], s[row base]`; a row of the strip is 7 x XW coalesced 256-byte loads held in
+// registers, the next row's loads are in flight while the current row is compared.  Per cell: one compare, one select of
+// the position code (r*8 + j, kept in XW registers that advance by 8 per row), one select of the value (its own bits:
+// -0 stays -0).  A clamped re-read repeats the bin's last cell and cannot win the strict compare; with NANSAFE a NaN
+// always wins (ATen) and the decode clamps.  Results go straight into the [channel][bin] LDS image.
+// (The direct path this replaces spent ~10 VALU instructions per cell on 64-bit address and index arithmetic.)
+template <int XW, bool NANSAFE>
+__device__ __forceinline__ void roi_task_wide(const char *__restrict__ imgc0, int pixbytes, int W, int lane, int x1, int y1, int x2,
+                                              int y2, float *__restrict__ sval, unsigned short *__restrict__ sidx)
+{
+    const int Lh = y2 - y1, Lw = x2 - x1;
+    int ws[RP], we[RP];
+    unsigned voff[RP][XW];
+#pragma unroll
+    for (int i = 0; i < RP; ++i) {
+        ws[i] = (i * Lw) / RP;                          // relative to x1 (uniform)
+        we[i] = ((i + 1) * Lw + RP - 1) / RP;
+#pragma unroll
+        for (int j = 0; j < XW; ++j) voff[i][j] = (unsigned)(min(ws[i] + j, we[i] - 1) * pixbytes + lane * 4);
+    }
+    auto load_row = [&](int y, float (&v)[RP][XW]) {
+        const char *rowg = imgc0 + (int64_t)(y * W + x1) * pixbytes;                   // uniform
+#pragma unroll
+        for (int i = 0; i < RP; ++i)
+#pragma unroll
+            for (int j = 0; j < XW; ++j) v[i][j] = *reinterpret_cast<const float *>(rowg + voff[i][j]);
+    };
+#pragma unroll 1
+    for (int ph = 0; ph < RP; ++ph) {
+        const int hs = y1 + (ph * Lh) / RP, he = y1 + ((ph + 1) * Lh + RP - 1) / RP;
+        float best[RP];
+        int code[RP], vcode[XW];
+#pragma unroll
+        for (int i = 0; i < RP; ++i) { best[i] = -INFINITY; code[i] = 0; }
+#pragma unroll
+        for (int j = 0; j < XW; ++j) vcode[j] = j;
+        auto scan_row = [&](const float (&v)[RP][XW]) {
+#pragma unroll
+            for (int j = 0; j < XW; ++j) {
+#pragma unroll
+                for (int i = 0; i < RP; ++i) {
+                    const float a = v[i][j];
+                    const bool g = NANSAFE ? ((a > best[i]) || (a != a)) : (a > best[i]);
+                    code[i] = g ? vcode[j] : code[i];
+                    best[i] = g ? a : best[i];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < XW; ++j) vcode[j] += 8;
+        };
+        // two row buffers, used alternately (the loop is unrolled by two so that neither is ever copied)
+        float ra[RP][XW], rb[RP][XW];
+        load_row(hs, ra);
+#pragma unroll 1
+        for (int y = hs; y < he; y += 2) {
+            load_row(min(y + 1, he - 1), rb);               // past the strip: a re-read whose result is not used
+            scan_row(ra);
+            if (y + 1 < he) {                               // uniform
+                load_row(min(y + 2, he - 1), ra);
+                scan_row(rb);
+            }
+        }
+        const int ibase = hs * W + x1;
+#pragma unroll
+        for (int i = 0; i < RP; ++i) {
+            sval[lane * RBINS + ph * RP + i] = best[i];
+            sidx[lane * RBINS + ph * RP + i] = (unsigned short)(ibase + (code[i] >> 3) * W + min(ws[i] + (code[i] & 7), we[i] - 1));
+        }
+    }
+}
+
 // A16: the argmax goes out as uint16 (argmax16) instead of int32 (argmax).  A compile-time choice: with both store
 // sequences in one kernel the int32 path ran 0.6-0.8 ms slower (the scheduler's interleaving of the output phase moved).
 template <int MODE, bool A16>
@@ -543,7 +623,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             // widest / tallest adaptive bin of a length L = 7q + r: q (r == 0), q + 1 (r == 1), q + 2 (r >= 2)
             const int qw = Lw / RP, rw = Lw - qw * RP, qh = Lh / RP, rh = Lh - qh * RP;
             const int maxw = qw + (rw > 1 ? 2 : rw), maxrows = qh + (rh > 1 ? 2 : rh);
-            staged = (R >= maxrows) && (Lwp <= 24) && (maxw <= 4 || (!may_nan && Lw <= 16)) && (cvalid == 64) && ((C & 3) == 0) &&
+            staged = (R >= maxrows) && (Lwp <= 24) && (maxw <= 4 || (!may_nan && Lw <= 16)) && (DG_FWD_STAGED_MAXW >= 24 || may_nan || Lw <= DG_FWD_STAGED_MAXW) && (cvalid == 64) && ((C & 3) == 0) &&
                      ((((uintptr_t)nhwc) & 15) == 0) && ((int64_t)H * W * C * 4 < (1ll << 31));
             if (staged) {
                 float oval[RBINS];
@@ -609,6 +689,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #pragma unroll
                 for (int i = 0; i < RBINS; ++i) sval[lane * RBINS + i] = oval[i];
                 emit();
+            }
+        }
+        if (MODE == DG_POOL_MAX && !staged && cvalid == 64 && (int64_t)H * W * C * 4 < (1ll << 31) && DG_FWD_WIDE) {
+            // ---- wide / tall crops, whole channel blocks: register-streamed rows, see roi_task_wide
+            const int qw = Lw / RP, rw = Lw - qw * RP;
+            const int maxw = qw + (rw > 1 ? 2 : rw);
+            if (maxw <= 8) {
+                const char *imgc0 = reinterpret_cast<const char *>(nhwc + ((int64_t)b * H * W) * C + c0);
+#define WIDE(XWV) do { if (may_nan) roi_task_wide<XWV, true>(imgc0, C * 4, W, lane, x1, y1, x2, y2, sval, sidx); \
+                       else roi_task_wide<XWV, false>(imgc0, C * 4, W, lane, x1, y1, x2, y2, sval, sidx); } while (0)
+                if (maxw <= 4) WIDE(4);
+                else if (maxw <= 6) WIDE(6);
+                else WIDE(8);
+#undef WIDE
+                emit();
+                staged = true;
             }
         }
         if (!staged) {
