@@ -477,9 +477,16 @@ __device__ __forceinline__ void roi_task_wide(const char *__restrict__ imgc0, in
 #pragma unroll
                 for (int i = 0; i < RP; ++i) {
                     const float a = v[i][j];
-                    const bool g = NANSAFE ? ((a > best[i]) || (a != a)) : (a > best[i]);
-                    code[i] = g ? vcode[j] : code[i];
-                    best[i] = g ? a : best[i];
+                    if (NANSAFE) {
+                        const bool g = (a > best[i]) || (a != a);
+                        code[i] = g ? vcode[j] : code[i];
+                        best[i] = g ? a : best[i];
+                    } else {
+                        // value by v_max (full rate; v_cmp / v_cndmask are half rate): equal to the selected value except
+                        // that max(-0, +0) = +0 while the strict compare keeps the earlier -0 -- repaired after the strip
+                        code[i] = (a > best[i]) ? vcode[j] : code[i];
+                        best[i] = vmaxf(best[i], a);
+                    }
                 }
             }
 #pragma unroll
@@ -498,10 +505,25 @@ __device__ __forceinline__ void roi_task_wide(const char *__restrict__ imgc0, in
             }
         }
         const int ibase = hs * W + x1;
+        int pos[RP];
+#pragma unroll
+        for (int i = 0; i < RP; ++i) pos[i] = ibase + (code[i] >> 3) * W + min(ws[i] + (code[i] & 7), we[i] - 1);
+        if (!NANSAFE) {
+            // a maximum of zero may carry the wrong sign (see scan_row): take the winning cell's own bits (rare, uniform branch)
+            bool anyz = false;
+#pragma unroll
+            for (int i = 0; i < RP; ++i) anyz = anyz || (best[i] == 0.0f);
+            if (__ballot(anyz) != 0ull) {
+#pragma unroll
+                for (int i = 0; i < RP; ++i)
+                    if (best[i] == 0.0f)
+                        best[i] = *reinterpret_cast<const float *>(imgc0 + (int64_t)pos[i] * pixbytes + lane * 4);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < RP; ++i) {
             sval[lane * RBINS + ph * RP + i] = best[i];
-            sidx[lane * RBINS + ph * RP + i] = (unsigned short)(ibase + (code[i] >> 3) * W + min(ws[i] + (code[i] & 7), we[i] - 1));
+            sidx[lane * RBINS + ph * RP + i] = (unsigned short)pos[i];
         }
     }
 }
@@ -699,9 +721,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 const char *imgc0 = reinterpret_cast<const char *>(nhwc + ((int64_t)b * H * W) * C + c0);
 #define WIDE(XWV) do { if (may_nan) roi_task_wide<XWV, true>(imgc0, C * 4, W, lane, x1, y1, x2, y2, sval, sidx); \
                        else roi_task_wide<XWV, false>(imgc0, C * 4, W, lane, x1, y1, x2, y2, sval, sidx); } while (0)
-                if (maxw <= 4) WIDE(4);
-                else if (maxw <= 6) WIDE(6);
-                else WIDE(8);
+                switch (maxw) {
+                case 1: case 2: case 3: case 4: WIDE(4); break;
+                case 5: WIDE(5); break;
+                case 6: WIDE(6); break;
+                case 7: WIDE(7); break;
+                default: WIDE(8); break;
+                }
 #undef WIDE
                 emit();
                 staged = true;
