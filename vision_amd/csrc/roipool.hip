@@ -528,9 +528,27 @@ __device__ __forceinline__ void roi_task_wide(const char *__restrict__ imgc0, in
     }
 }
 
+// Which code serves a max-mode task: 0 = LDS-ring strips (roi_task_exact / roi_task_staged), 1 = register-streamed rows
+// (roi_task_wide, run by the kernel's PART 1 instantiation), 2 = the direct path.  One definition for both instantiations.
+__device__ __forceinline__ int fwd_max_task_class(int Lw, int Lh, bool may_nan, int cvalid, int C, bool aligned16, bool small_image)
+{
+    const int Lwp = (Lw + 3) & ~3;
+    const int R = RING_PX / Lwp;
+    // widest / tallest adaptive bin of a length L = 7q + r: q (r == 0), q + 1 (r == 1), q + 2 (r >= 2)
+    const int qw = Lw / RP, rw = Lw - qw * RP, qh = Lh / RP, rh = Lh - qh * RP;
+    const int maxw = qw + (rw > 1 ? 2 : rw), maxrows = qh + (rh > 1 ? 2 : rh);
+    const bool staged = (R >= maxrows) && (Lwp <= 24) && (maxw <= 4 || (!may_nan && Lw <= 16)) && (cvalid == 64) && ((C & 3) == 0) &&
+                        aligned16 && small_image;
+    if (staged) return 0;
+    if (DG_FWD_WIDE && cvalid == 64 && small_image && maxw <= 8) return 1;
+    return 2;
+}
+
 // A16: the argmax goes out as uint16 (argmax16) instead of int32 (argmax).  A compile-time choice: with both store
 // sequences in one kernel the int32 path ran 0.6-0.8 ms slower (the scheduler's interleaving of the output phase moved).
-template <int MODE, bool A16>
+// PART 0: every task but the class-1 ones (they are skipped); PART 1 (max mode only): the class-1 tasks alone -- a kernel of
+// its own, because with roi_task_wide compiled into the main kernel the narrow-crop path ran 3 % slower (19.2 -> 19.9 ms).
+template <int MODE, bool A16, int PART>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_roipool_fwd(const float *__restrict__ nhwc, int C, int H, int W,
                                                     const int32_t *__restrict__ win, int cblocks, int64_t ntasks,
                                                     const int32_t *__restrict__ nan_flag,
@@ -549,8 +567,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #endif
     // Persistent single-wave workgroups.  Task = (RoI, 64-channel block), channel block fastest; the grid is a
     // multiple of 8, so a workgroup (and the XCD it sits on, blockIdx % 8) keeps one channel slice of the map.
-#pragma unroll 1
-    for (int64_t task = blockIdx.x; task < ntasks; task += gridDim.x) {
+    const bool aligned16 = (((uintptr_t)nhwc) & 15) == 0, small_image = (int64_t)H * W * C * 4 < (1ll << 31);
+    auto run_task = [&](int64_t task) {
         // opaque per task: otherwise every lane-derived LDS/global address of the loop body (about 100 of them) is
         // hoisted out of the task loop and held in registers for the kernel's lifetime
         int lane = lane0;
@@ -639,14 +657,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         STAMP_ADD(5, te0, te1);
         };
         bool staged = false;
-        if (MODE == DG_POOL_MAX) {
+        const int kind = (MODE == DG_POOL_MAX) ? fwd_max_task_class(Lw, Lh, may_nan, cvalid, C, aligned16, small_image) : 2;
+        if (PART == 0 && kind == 1) return;               // the PART 1 launch does this task
+        if (MODE == DG_POOL_MAX && PART == 0) {
             const int Lwp = (Lw + 3) & ~3;
             const int R = RING_PX / Lwp;
-            // widest / tallest adaptive bin of a length L = 7q + r: q (r == 0), q + 1 (r == 1), q + 2 (r >= 2)
-            const int qw = Lw / RP, rw = Lw - qw * RP, qh = Lh / RP, rh = Lh - qh * RP;
-            const int maxw = qw + (rw > 1 ? 2 : rw), maxrows = qh + (rh > 1 ? 2 : rh);
-            staged = (R >= maxrows) && (Lwp <= 24) && (maxw <= 4 || (!may_nan && Lw <= 16)) && (DG_FWD_STAGED_MAXW >= 24 || may_nan || Lw <= DG_FWD_STAGED_MAXW) && (cvalid == 64) && ((C & 3) == 0) &&
-                     ((((uintptr_t)nhwc) & 15) == 0) && ((int64_t)H * W * C * 4 < (1ll << 31));
+            const int qw = Lw / RP, rw = Lw - qw * RP;
+            const int maxw = qw + (rw > 1 ? 2 : rw);
+            staged = kind == 0;
             if (staged) {
                 float oval[RBINS];
                 int oidx[RBINS];
@@ -690,7 +708,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 emit();
             }
         }
-        if (MODE == DG_POOL_AVG) {
+        if (MODE == DG_POOL_AVG && PART == 0) {
             const int Lwp = (Lw + 3) & ~3;
             const int R = RING_PX / Lwp;
             const int qh = Lh / RP, rh = Lh - qh * RP;
@@ -713,11 +731,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 emit();
             }
         }
-        if (MODE == DG_POOL_MAX && !staged && cvalid == 64 && (int64_t)H * W * C * 4 < (1ll << 31) && DG_FWD_WIDE) {
+        if (MODE == DG_POOL_MAX && PART == 1) {
             // ---- wide / tall crops, whole channel blocks: register-streamed rows, see roi_task_wide
             const int qw = Lw / RP, rw = Lw - qw * RP;
             const int maxw = qw + (rw > 1 ? 2 : rw);
-            if (maxw <= 8) {
+            {
                 const char *imgc0 = reinterpret_cast<const char *>(nhwc + ((int64_t)b * H * W) * C + c0);
 #define WIDE(XWV) do { if (may_nan) roi_task_wide<XWV, true>(imgc0, C * 4, W, lane, x1, y1, x2, y2, sval, sidx); \
                        else roi_task_wide<XWV, false>(imgc0, C * 4, W, lane, x1, y1, x2, y2, sval, sidx); } while (0)
@@ -733,7 +751,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
                 staged = true;
             }
         }
-        if (!staged) {
+        if (PART == 0 && !staged) {
             // ---- direct path (any crop size, partial channel blocks): reads the map from L2/HBM per bin
             const int c = c0 + (lane < cvalid ? lane : cvalid - 1);
             const float *base = nhwc + (int64_t)b * H * W * C + c;
@@ -764,6 +782,39 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         }
         STAMP(tb);
         STAMP_ADD(4, ta, tb);                                 // whole task; slot 5 (output phase) is part of it
+    };
+    if (PART == 0) {
+#pragma unroll 1
+        for (int64_t task = blockIdx.x; task < ntasks; task += gridDim.x) run_task(task);
+    } else {
+        // Class-1 tasks are usually few and far between: 64 tasks are classified at once, one per lane, and only the
+        // flagged ones are run (a wave-serial test per task would cost a dependent global load each).  A wave keeps one
+        // channel block (and with it its XCD's slice of the maps) when the grid is a multiple of cblocks.
+        const bool keep_cb = (gridDim.x % cblocks) == 0;
+        const int64_t nrois = ntasks / cblocks;
+        const int64_t units = keep_cb ? nrois : ntasks;                       // what a lane indexes: RoIs or tasks
+        const int64_t wave0 = keep_cb ? (int64_t)(blockIdx.x / cblocks) : (int64_t)blockIdx.x;
+        const int64_t nwaves = keep_cb ? (int64_t)(gridDim.x / cblocks) : (int64_t)gridDim.x;
+        const int mycb = keep_cb ? (int)(blockIdx.x % cblocks) : 0;
+#pragma unroll 1
+        for (int64_t base = wave0 * 64; base < units; base += nwaves * 64) {
+            const int64_t u = base + lane0;
+            bool flag = false;
+            if (u < units) {
+                const int64_t roi = keep_cb ? u : u / cblocks;
+                const int cbk = keep_cb ? mycb : (int)(u % cblocks);
+                const int32_t *w = win + 5 * roi;
+                const int cv = (C - cbk * 64) < 64 ? (C - cbk * 64) : 64;
+                flag = fwd_max_task_class(w[2] - w[0], w[3] - w[1], may_nan, cv, C, aligned16, small_image) == 1;
+            }
+            unsigned long long m = __ballot(flag);
+            while (m) {
+                const int l = __builtin_ctzll(m);
+                m &= m - 1;
+                const int64_t uu = base + l;
+                run_task(keep_cb ? uu * cblocks + mycb : uu);
+            }
+        }
     }
 #ifdef DG_STAMPS
     STAMP(tk1);
@@ -1170,11 +1221,12 @@ static int roipool_fwd(const float *img_nhwc, int64_t B, int64_t C, int64_t H, i
     const int64_t ntasks = n * cblocks;
     const int64_t maxgrid = 256 * 8;                   // 256 CUs x 8 resident single-wave workgroups (18.8 KB LDS each)
     dim3 grid((unsigned)(ntasks < maxgrid ? ntasks : maxgrid));
-#define FWD_LAUNCH(MODE, A16) \
-    hipLaunchKernelGGL((k_roipool_fwd<MODE, A16>), grid, dim3(64), 0, st, img_nhwc, (int)C, (int)H, (int)W, win, (int)cblocks, ntasks, nan_flag, out, argmax, argmax16, vec_ok)
-    if (mode == DG_POOL_MAX && argmax16) FWD_LAUNCH(DG_POOL_MAX, true);
-    else if (mode == DG_POOL_MAX) FWD_LAUNCH(DG_POOL_MAX, false);
-    else FWD_LAUNCH(DG_POOL_AVG, false);
+#define FWD_LAUNCH(MODE, A16, PART) \
+    hipLaunchKernelGGL((k_roipool_fwd<MODE, A16, PART>), grid, dim3(64), 0, st, img_nhwc, (int)C, (int)H, (int)W, win, (int)cblocks, ntasks, nan_flag, out, argmax, argmax16, vec_ok)
+    // max mode: the main kernel, then the wide-crop kernel over the tasks the first one left (disjoint outputs)
+    if (mode == DG_POOL_MAX && argmax16) { FWD_LAUNCH(DG_POOL_MAX, true, 0); if (DG_FWD_WIDE) FWD_LAUNCH(DG_POOL_MAX, true, 1); }
+    else if (mode == DG_POOL_MAX) { FWD_LAUNCH(DG_POOL_MAX, false, 0); if (DG_FWD_WIDE) FWD_LAUNCH(DG_POOL_MAX, false, 1); }
+    else FWD_LAUNCH(DG_POOL_AVG, false, 0);
 #undef FWD_LAUNCH
     DG_CHECK_LAUNCH("k_roipool_fwd");
     return DG_OK;
