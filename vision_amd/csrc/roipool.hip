@@ -19,6 +19,9 @@
 #ifndef DG_FWD_STAGED_MAXW
 #define DG_FWD_STAGED_MAXW 24
 #endif
+#ifndef DG_FWD_RECOVER_V2
+#define DG_FWD_RECOVER_V2 1
+#endif
 #ifndef DG_FWD_WIDE
 #define DG_FWD_WIDE 1
 #endif
@@ -301,6 +304,18 @@ __device__ __forceinline__ void roi_task_exact(char *smem, const char *__restric
             int rs = slot + brow[i];                       // ring slot of the winning row (per lane)
             rs = (rs >= R) ? rs - R : rs;
             const char *rowp = lbase + rs * rowbytes;
+#if DG_FWD_RECOVER_V2
+            // first cell of the winning row that equals the maximum: the last one is implied, a one-cell bin needs nothing.
+            // The value is the running maximum itself; only a maximum of zero can differ from the winning cell's bits
+            // (max(-0,+0)), and the caller repairs those after the task (rare, outside the strips).
+            int c = w - 1;
+#pragma unroll
+            for (int j = w - 2; j >= 0; --j) {
+                const float a = *(const float *)(rowp + (s + j) * 256);
+                c = (a == best[i]) ? j : c;
+            }
+            oval[ph * RP + i] = best[i];
+#else
             int c = 0;
             float bv = best[i];
 #pragma unroll
@@ -311,6 +326,7 @@ __device__ __forceinline__ void roi_task_exact(char *smem, const char *__restric
                 bv = hit ? a : bv;
             }
             oval[ph * RP + i] = bv;
+#endif
             oidx[ph * RP + i] = ibase + brow[i] * W + s + c;
         }
         // The reads above must have returned before the next strip issues LDS-DMA into the rows they came from:
@@ -697,6 +713,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #undef STAGED
 #undef EXACT
                 STAMP(tw0);
+#if DG_FWD_RECOVER_V2
+                if (!may_nan) {
+                    // signed zeros: a zero maximum takes the winning cell's own bits (min over |values| by v_min3: 24 ops)
+                    float mz = fabsf(oval[0]);
+#pragma unroll
+                    for (int i = 1; i < RBINS; i += 2) mz = fminf(mz, fminf(fabsf(oval[i]), fabsf(oval[i + 1])));
+                    if (__ballot(mz == 0.0f) != 0ull) {
+#pragma unroll
+                        for (int i = 0; i < RBINS; ++i)
+                            if (oval[i] == 0.0f) oval[i] = *reinterpret_cast<const float *>(imgc0 + (int64_t)oidx[i] * (C * 4) + lane * 4);
+                    }
+                }
+#endif
                 // all ring reads are done (results are in registers): the transpose buffer may overwrite the ring
 #pragma unroll
                 for (int i = 0; i < RBINS; ++i) {
