@@ -218,8 +218,9 @@ def cpu_baseline_frcnn(images=12, n_rois=2000):
     ref = None
     try:    # the reference's own Python, timed in the build container by tools/time_reference_cpu.py (numbers only travel)
         rj = json.load(open(os.path.join(ROOT, "profiles", "r02_reference_cpu.json")))
-        ms = {r["path"].split(",")[0]: r["median_ms"] for r in rj["rows"]}
-        step_ms = ms["max variant forward + autograd backward"] + [v for k, v in ms.items() if k.startswith("nms")][0]
+        rows = {r["path"]: r["median_ms"] for r in rj["rows"]}
+        step_ms = ([v for k, v in rows.items() if k.startswith("max variant forward + autograd backward")][0] +
+                   [v for k, v in rows.items() if k.startswith("nms") and "thr 0.7" in k][0])
         ref = {"value": 2000 / step_ms * 1e3, "unit": "RoIs/s", "cores": rj["meta"]["torch_threads"],
                "what": "reference functions (slowroipool with AdaptiveMaxPool2d fwd + autograd bwd, nms thr 0.7) on one config-1 image, "
                        "build container, median of %d" % rj["meta"]["runs"]}
