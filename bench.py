@@ -356,6 +356,18 @@ def extra_kmeans(d, n_total=10_000_000, iters=30):
     lo, hi = sh.shard_range(n_total, d.rank, d.world)
     per = hi - lo
     shard = torch.from_numpy(wh_all[lo:hi]).to(d.dev)
+    eager = None
+    if d.world > 1 and not d.rehearse:
+        # first the loop issued eagerly (launch + RCCL all-reduce per iteration from Python): the number that exists even if
+        # capturing RCCL into a HIP graph misbehaves on this node (the watchdog in main() then still has a k-means figure)
+        os.environ["DG_KMEANS_GRAPH"] = "0"
+        ke = cluster.kmean(5, 42)
+        ke.fit(shard, init_centers=init, fixed_iters=iters)
+        sec_e = min(Dist.timed(d, lambda: ke._run_iters(0, iters), 1, 0) for _ in range(5))
+        eager = {"iters_per_s": iters / sec_e, "ms_per_iter": sec_e / iters * 1e3, "state": ke.graph_state}
+        PARTIAL["config4_kmeans_10M"] = {"eager_loop": eager, "ranks": d.world, "note": "graph-captured loop did not finish"}
+        os.environ["DG_KMEANS_GRAPH"] = "1"
+        del ke
     km = cluster.kmean(5, 42, reduce_device="cpu" if d.rehearse else None)   # rehearsal: gloo reduces host tensors
     km.fit(shard, init_centers=init, fixed_iters=iters)     # warm-up (RCCL channels, graph capture); leaves the device state
     sec = min(Dist.timed(d, lambda: km._run_iters(0, iters), 1, 0) for _ in range(5))   # the Lloyd iterations proper
@@ -365,7 +377,7 @@ def extra_kmeans(d, n_total=10_000_000, iters=30):
          "sharded_loop": km.graph_state if d.world > 1 else "single device: dg_kmeans_iou_run",
          "device_ms_per_iter_this_shard": ms, "iter_hbm_frac": (12.0 * per) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
          "iter_valu_frac": valu_frac("k_kmeans_step", per, ms),
-         "centers": km.cluster_centers_.round(6).tolist(),
+         "centers": km.cluster_centers_.round(6).tolist(), "eager_loop": eager,
          "note": "config 4, strong scaling: 10M boxes sharded; per iteration ONE launch (the centroid update is the prologue of "
                  "the next step) + ONE 17 x int64 all-reduce, the 30 iterations replayed as one HIP graph when capture succeeds; "
                  "timed: best of 5 runs of 30 iterations, device-resident; the inertia sum is formed by the last iteration of a "
@@ -397,6 +409,36 @@ def extra_kmeans(d, n_total=10_000_000, iters=30):
 
 
 T0 = time.perf_counter()
+PARTIAL = {}          # side results a section publishes before a step that could hang (read by the watchdog)
+
+
+def start_watchdog(d, line, extra, seconds):
+    """The side configurations run after the primary measurement.  Should one of them hang (a collective that never
+    returns, say), every rank leaves after `seconds`: rank 0 prints the primary line with what the extras had produced."""
+    import threading
+
+    def fire():
+        try:
+            if d.rank == 0:
+                ex = dict(extra)
+                for k, v in PARTIAL.items():
+                    ex.setdefault(k, v)
+                ex["watchdog"] = f"side configurations did not finish within {seconds} s; primary line printed by the watchdog"
+                out = dict(line)
+                out["extra"] = ex
+                out.setdefault("roofline", None)
+                out.setdefault("cpu_baseline", None)
+                sys.stdout.write(json.dumps(out, default=str) + "\n")
+                sys.stdout.flush()
+            print(f"[bench rank {d.rank}] watchdog: leaving after {seconds} s in the side configurations", file=sys.stderr, flush=True)
+        except BaseException as e:  # noqa: BLE001
+            print(f"[bench rank {d.rank}] watchdog failed to print the line: {e!r}", file=sys.stderr, flush=True)
+        finally:
+            os._exit(0)
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
 
 
 def trace(d, msg):
@@ -505,6 +547,8 @@ def main():
     del w
     torch.cuda.empty_cache()
     extra = {"phases_ms_rank0": phases, "grad_out_aliases_out": gout_alias, "config3_uint16_argmax": a16}
+    line["roofline"] = roofline
+    dog = start_watchdog(d, line, extra, int(os.environ.get("DG_BENCH_EXTRAS_TIMEOUT", "420")))
 
     def side(name, fn):
         # a side configuration that fails is reported as such; it must not cost the primary line
@@ -549,6 +593,7 @@ def main():
     cpu = None
     if d.rank == 0 and d.world == 1 and not a.no_cpu:
         cpu = cpu_baseline_frcnn()
+    dog.cancel()
     line.update({"roofline": roofline, "cpu_baseline": cpu, "extra": extra})
     finish(d, line)
 
