@@ -28,17 +28,18 @@ for it in range(rounds):
     idx = rng.integers(0, B, n).astype(np.int64)
     x = torch.from_numpy(img).cuda()
     win, st = ops.roi_windows(rois, idx, B, H, W, x.device)
+    P = 7 if rng.random() < 0.7 else [3, (2, 5), 10, 1, (9, 4)][int(rng.integers(5))]      # mostly the tuned 7x7 path
     for mode in ("max", "avg"):
-        out, arg = ops.roipool_forward(x, win, mode)
-        want, warg = oracle.roipool_fwd(img, rois, idx, 7, mode)
+        out, arg = ops.roipool_forward(x, win, mode, P=P)
+        want, warg = oracle.roipool_fwd(img, rois, idx, P, mode)
         if mode == "max":
-            chk("roi fwd max", np.array_equal(out.cpu().numpy(), want, equal_nan=True) and np.array_equal(arg.cpu().numpy(), warg), (B, Cc, H, W, n))
+            chk("roi fwd max", np.array_equal(out.cpu().numpy(), want, equal_nan=True) and np.array_equal(arg.cpu().numpy(), warg), (B, Cc, H, W, n, P))
         else:
             chk("roi fwd avg", np.allclose(out.cpu().numpy(), want, rtol=1e-5, atol=1e-5, equal_nan=True), (B, Cc, H, W, n))
         if not np.isnan(img).any():
             g = rng.standard_normal(want.shape, dtype=np.float32)
-            gin = ops.roipool_backward(torch.from_numpy(g).cuda(), arg, win, img.shape, mode).cpu().numpy()
-            wgin = oracle.roipool_bwd(g, warg, img.shape, rois, idx, 7, mode)
+            gin = ops.roipool_backward(torch.from_numpy(g).cuda(), arg, win, img.shape, mode, P=P).cpu().numpy()
+            wgin = oracle.roipool_bwd(g, warg, img.shape, rois, idx, P, mode)
             chk("roi bwd " + mode, np.allclose(gin, wgin, rtol=1e-4, atol=1e-3), (B, Cc, H, W, n))
     # ---- NMS: ragged batch, random sizes crossing the kernel-selection boundaries, random threshold
     nb = int(rng.integers(1, 5)); N = int(rng.choice([5, 98, 447, 449, 700, 2000, 4100, 9000]))
@@ -53,6 +54,20 @@ for it in range(rounds):
     for i in range(nb):
         wantk = oracle.nms(boxes[i, :counts[i]], scores[i, :counts[i]], thr, quirk)
         chk("nms", cnt[i] == len(wantk) and np.array_equal(keep[i, :cnt[i]], wantk), (N, int(counts[i]), thr, quirk))
+    # ---- per-class NMS on the same boxes: the oracle's nms applied per class
+    Ccls = int(rng.choice([1, 3, 20, 80]))
+    labels = rng.integers(0, Ccls, (nb, N)).astype(np.int64)
+    keep, cnt, ccnt, stt = ops.nms_batched_per_class(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), torch.from_numpy(labels).cuda(),
+                                                     Ccls, torch.from_numpy(counts), thr, quirk)
+    keep, cnt = keep.cpu().numpy(), cnt.cpu().numpy()
+    for i in range(nb):
+        m = int(counts[i]); wk = []
+        for c in range(Ccls):
+            ii = np.flatnonzero(labels[i, :m] == c)
+            if ii.size:
+                wk.append(ii[oracle.nms(boxes[i, ii], scores[i, ii], thr, quirk)])
+        wk = np.concatenate(wk) if wk else np.zeros(0, np.int64)
+        chk("nms per class", cnt[i] == len(wk) and np.array_equal(keep[i, :cnt[i]], wk), (N, m, Ccls, thr, quirk))
     # ---- IoU pairwise / elementwise
     a = wl.random_boxes(int(rng.integers(1 << 30)), int(rng.integers(1, 400))); b = wl.random_boxes(int(rng.integers(1 << 30)), int(rng.integers(1, 3000)))
     chk("pairwise", np.array_equal(ops.iou_pairwise(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()).cpu().numpy(), oracle.iou_pairwise(a, b)))
@@ -66,6 +81,14 @@ for it in range(rounds):
     l2 = torch.from_numpy(lab0).cuda(); a2 = torch.zeros(3 * k + 2, dtype=torch.int64, device="cuda")
     ops.kmeans_step(whd, torch.from_numpy(cent).cuda(), l2, a2)
     chk("kmeans", np.array_equal(a2.cpu().numpy(), acc) and np.array_equal(l2.cpu().numpy(), lab), (nk, k, off))
+    # ---- the sharded Lloyd loop on the device (dg_kmeans_iou_iter / _finish; no process group: one shard), fixed iterations
+    if it % 4 == 0:
+        from vision_amd import cluster
+        k2 = int(rng.choice([2, 5, 9, 13])); n2 = int(rng.integers(k2 + 1, 120000)); its = int(rng.integers(1, 12))
+        wh2 = wl.anchor_wh(int(rng.integers(1 << 30)), n2)
+        km = cluster.kmean(k2, 42, sharded=True).fit(torch.from_numpy(wh2).cuda(), fixed_iters=its)
+        c2, l2_, n_it, inert = oracle.kmeans_fit(wh2, k2, 42, fixed_iters=its)
+        chk("kmeans sharded loop", np.array_equal(km.cluster_centers_, c2) and np.array_equal(km.labels_, l2_) and abs(km.inertia_ - inert) < 1e-9, (n2, k2, its))
     # ---- YOLOv1 decode + loss
     bs = int(rng.integers(1, 40)); Cn = int(rng.choice([1, 5, 20]))
     out, tgt = wl.yolo1_batch(int(rng.integers(1 << 30)), bs, Cn)
