@@ -212,7 +212,7 @@ class kmean:
             try:
                 torch.cuda.synchronize(be.wh.device)
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):   # RCCL's watchdog thread keeps polling its events
                     self._sharded_chunk(slot0, count)
                 self._graphs[key] = g
                 self.graph_state = "captured"
