@@ -12,7 +12,7 @@ idx = torch.arange(images, device=dev).repeat_interleave(2000)
 win, st = ops.roi_windows(rois, idx, images, 38, 50, dev)
 nhwc, nanf = ops.to_nhwc(img)
 out, arg = ops.roipool_forward(img, win, "max", nhwc=nhwc, nan_flag=nanf)
-def t(fn, it=6):
+def t(fn, it=int(__import__("os").environ.get("AB_IT", "6"))):
     fn(); torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True); a.record()
     for _ in range(it): fn()
