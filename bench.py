@@ -574,10 +574,16 @@ def main():
     dst = torch.empty_like(src)
     t_copy = ev_median(lambda: dst.copy_(src), 20, 5)
     copy_gbps = 2 * src.numel() * 4 / (t_copy * 1e-3) / 1e9
+    # and what a plain device fill reaches: the forward kernel writes 99 % of its bytes, so the store rate of the box is its
+    # real ceiling (tools/ubench/store_bw.hip: 5.4-5.7 TB/s for every pattern and launch shape tried)
+    t_fill = ev_median(lambda: dst.fill_(1.0), 20, 5)
+    fill_gbps = dst.numel() * 4 / (t_fill * 1e-3) / 1e9
     del src, dst
     torch.cuda.empty_cache()
     roofline["d2d_copy_GBps"] = copy_gbps
     roofline["frac_of_d2d_copy"] = achieved / copy_gbps
+    roofline["device_fill_GBps"] = fill_gbps
+    roofline["frac_of_device_fill"] = achieved / fill_gbps
 
     if not a.no_extras:
         if d.rank == 0:

@@ -1,0 +1,69 @@
+// Store-bandwidth ceiling for the RoI forward's output pattern (never shipped).
+//   hipcc -O3 --offload-arch=gfx950 tools/ubench/store_bw.hip -o tools/ubench/store_bw
+// Patterns: 0 = plain linear fill (grid-stride, 16 B per lane); 1 = the forward kernel's: persistent single-wave
+// workgroups, task = 12.25 KB chunk of `out` + the same chunk of `arg`, chunk index = task (block-strided);
+// 2 = as 1 but a task writes one 24.5 KB chunk (out and arg interleaved per task: what a fused output would look like).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+typedef float v4f __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ void st(float *p, v4f v)
+{
+    if (NT) __builtin_nontemporal_store(v, reinterpret_cast<v4f *>(p));
+    else *reinterpret_cast<v4f *>(p) = v;
+}
+template <bool NT> __global__ void k_linear(float *a, size_t n4)
+{
+    const v4f v = {1.f, 2.f, 3.f, (float)threadIdx.x};
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) st<NT>(a + 4 * i, v);
+}
+template <bool NT, int PAT> __global__ __launch_bounds__(64) void k_tasks(float *out, float *arg, long ntasks)
+{
+    const int lane = threadIdx.x;
+    const v4f v = {1.f, 2.f, 3.f, (float)lane};
+    for (long t = blockIdx.x; t < ntasks; t += gridDim.x) {
+        float *o = (PAT == 1 ? out + t * 3136 : out + t * 6272) + lane * 4;
+        float *a = (PAT == 1 ? arg + t * 3136 : out + t * 6272 + 3136) + lane * 4;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) st<NT>(o + k * 256, v);
+        if (lane < 16) st<NT>(o + 12 * 256, v);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) st<NT>(a + k * 256, v);
+        if (lane < 16) st<NT>(a + 12 * 256, v);
+    }
+}
+int main(int argc, char **argv)
+{
+    const long ntasks = 512000L * 8;                 // config 3: 256 images x 2000 RoIs x 8 channel blocks
+    const size_t half = (size_t)ntasks * 3136 * 4;   // 51.4 GB
+    float *buf;
+    if (hipMalloc(&buf, 2 * half) != hipSuccess) { printf("alloc failed\n"); return 1; }
+    float *out = buf, *arg = buf + half / 4;
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    auto timeit = [&](const char *name, auto launch) {
+        launch(); hipDeviceSynchronize();
+        float best = 1e9f;
+        for (int r = 0; r < 3; ++r) {
+            hipEventRecord(e0); launch(); hipEventRecord(e1); hipEventSynchronize(e1);
+            float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best;
+        }
+        printf("%-44s %8.3f ms  %6.2f TB/s\n", name, best, 2.0 * half / best / 1e9);
+    };
+    for (int blocks : {2048, 4096, 8192, 65536}) {
+        char nm[96];
+        snprintf(nm, sizeof nm, "linear nt, %d x 256 threads", blocks);
+        timeit(nm, [&] { k_linear<true><<<blocks, 256>>>(buf, 2 * half / 16); });
+        snprintf(nm, sizeof nm, "linear plain, %d x 256 threads", blocks);
+        timeit(nm, [&] { k_linear<false><<<blocks, 256>>>(buf, 2 * half / 16); });
+    }
+    for (int waves : {1024, 2048, 3072, 4096, 8192}) {
+        char nm[96];
+        snprintf(nm, sizeof nm, "forward pattern nt, %d waves", waves);
+        timeit(nm, [&] { k_tasks<true, 1><<<waves, 64>>>(out, arg, ntasks); });
+        snprintf(nm, sizeof nm, "forward pattern plain, %d waves", waves);
+        timeit(nm, [&] { k_tasks<false, 1><<<waves, 64>>>(out, arg, ntasks); });
+        snprintf(nm, sizeof nm, "fused 24.5 KB chunks nt, %d waves", waves);
+        timeit(nm, [&] { k_tasks<true, 2><<<waves, 64>>>(out, arg, ntasks); });
+    }
+    return 0;
+}
