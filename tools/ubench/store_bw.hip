@@ -17,6 +17,15 @@ template <bool NT> __global__ void k_linear(float *a, size_t n4)
     const v4f v = {1.f, 2.f, 3.f, (float)threadIdx.x};
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) st<NT>(a + 4 * i, v);
 }
+template <bool NT> __global__ void k_linear_read(const float *a, size_t n4, float *sink)
+{
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const v4f v = NT ? __builtin_nontemporal_load(reinterpret_cast<const v4f *>(a + 4 * i)) : *reinterpret_cast<const v4f *>(a + 4 * i);
+        acc += v;
+    }
+    if (acc.x + acc.y + acc.z + acc.w == 1.2345e-30f) sink[0] = acc.x;
+}
 template <bool NT, int PAT> __global__ __launch_bounds__(64) void k_tasks(float *out, float *arg, long ntasks)
 {
     const int lane = threadIdx.x;
@@ -55,6 +64,16 @@ int main(int argc, char **argv)
         timeit(nm, [&] { k_linear<true><<<blocks, 256>>>(buf, 2 * half / 16); });
         snprintf(nm, sizeof nm, "linear plain, %d x 256 threads", blocks);
         timeit(nm, [&] { k_linear<false><<<blocks, 256>>>(buf, 2 * half / 16); });
+    }
+    if (argc > 1) {
+        for (int blocks : {2048, 4096, 8192, 65536}) {
+            char nm[96];
+            snprintf(nm, sizeof nm, "linear read plain, %d x 256 threads", blocks);
+            timeit(nm, [&] { k_linear_read<false><<<blocks, 256>>>(buf, 2 * half / 16, buf); });
+            snprintf(nm, sizeof nm, "linear read nt, %d x 256 threads", blocks);
+            timeit(nm, [&] { k_linear_read<true><<<blocks, 256>>>(buf, 2 * half / 16, buf); });
+        }
+        return 0;
     }
     for (int waves : {1024, 2048, 3072, 4096, 8192}) {
         char nm[96];
