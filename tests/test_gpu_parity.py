@@ -486,6 +486,12 @@ def test_roipool_every_crop_width_with_ties(va, oracle, with_nan):
     assert not bad.any(), sorted(set((wins[:, 2] - wins[:, 0])[bad.reshape(len(wins), -1).any(1)]))
     assert np.array_equal(np.isnan(got), np.isnan(want))
     assert np.array_equal(arg.cpu().numpy(), warg)
+    # the uint16-argmax kernel is an instantiation of its own (strips share their boundary row there): same bits, same indices
+    out16, arg16 = ops.roipool_forward(x, win, "max", argmax_dtype=torch.int16)
+    got16 = out16.cpu().numpy()
+    assert np.array_equal(got16.view(np.uint32)[~np.isnan(want)], want.view(np.uint32)[~np.isnan(want)])
+    assert np.array_equal(np.isnan(got16), np.isnan(want))
+    assert np.array_equal(ops.argmax_i32(arg16).cpu().numpy(), warg)
 
 
 def test_roipool_avg_every_crop_width(va, oracle):
@@ -736,6 +742,29 @@ def test_roipool_uint16_argmax_equals_int32(va, C, n):
     g32 = ops.roipool_backward(g, a32, win, img.shape, "max")
     g16 = ops.roipool_backward(g, a16, win, img.shape, "max")
     assert torch.allclose(g32, g16, rtol=1e-4, atol=1e-3)                       # LDS accumulation order is not fixed
+
+
+def test_roipool_uint16_argmax_every_width_and_height(va, oracle):
+    """every crop width 1..24 x every crop height 1..38 through the uint16-argmax kernel (strip-sharing code: the cases differ
+    by height mod 7) on a tie-rich map with both zeros, against the oracle."""
+    from vision_amd import ops
+    rng = np.random.default_rng(23)
+    B, C, H, W = 1, 64, 38, 50
+    levels = np.array([-1.0, -0.0, 0.0, 0.5, 1.0, 2.0], np.float32)
+    img = levels[rng.integers(0, len(levels), (B, C, H, W))]
+    wins = np.array([(x1, y1, x1 + lw, y1 + lh) for lw in range(1, 25) for lh in range(1, H + 1)
+                     for x1, y1 in [(int(rng.integers(0, W - lw + 1)), int(rng.integers(0, H - lh + 1)))]], np.int64)
+    rois = np.stack([(wins[:, 0] + 0.25) / W, (wins[:, 1] + 0.25) / H, (wins[:, 2] - 0.25) / W, (wins[:, 3] - 0.25) / H], 1)
+    idx = np.zeros(len(wins), np.int64)
+    x = torch.from_numpy(img).cuda()
+    win, status = ops.roi_windows(rois, idx, B, H, W, x.device)
+    assert int(status.item()) == 0 and np.array_equal(win.cpu().numpy()[:, :4], wins)
+    want, warg = oracle.roipool_fwd(img, rois, idx, 7, "max")
+    out16, arg16 = ops.roipool_forward(x, win, "max", argmax_dtype=torch.int16)
+    assert np.array_equal(out16.cpu().numpy().view(np.uint32), want.view(np.uint32))
+    assert np.array_equal(ops.argmax_i32(arg16).cpu().numpy(), warg)
+    out32, arg32 = ops.roipool_forward(x, win, "max")
+    assert np.array_equal(out32.cpu().numpy().view(np.uint32), want.view(np.uint32)) and np.array_equal(arg32.cpu().numpy(), warg)
 
 
 # ------------------------------------------------------------------ k-means

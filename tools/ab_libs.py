@@ -1,4 +1,4 @@
-"""A/B of the 7x7 max forward (AB_OP=fwd, default) or backward (AB_OP=bwd) between builds of the library, in ONE process on the SAME buffers, launches interleaved
+"""A/B of the 7x7 max forward (AB_OP=fwd, default; fwd16 = uint16 argmax) or backward (AB_OP=bwd / bwd16) between builds of the library, in ONE process on the SAME buffers, launches interleaved
 (run-to-run and buffer-placement noise on a box is several per cent, more than most kernel changes):
     python tools/ab_libs.py vision_amd/libdetgeom.so vision_amd/libexp_x.so [...]
 Prints per library the median / min of `rounds` timings of `it` launches each, and checks that the outputs agree."""
@@ -18,30 +18,31 @@ nhwc, nanf = ops.to_nhwc(img)
 n = win.shape[0]
 out = torch.empty((n, 512, 7, 7), device=dev); arg = torch.empty((n, 512, 7, 7), dtype=torch.int32, device=dev)
 op = os.environ.get("AB_OP", "fwd")
-sym = "dg_roipool_fwd_f32" if op == "fwd" else "dg_roipool_bwd_f32"
+sym = {"fwd": "dg_roipool_fwd_f32", "bwd": "dg_roipool_bwd_f32", "fwd16": "dg_roipool_fwd_a16_f32", "bwd16": "dg_roipool_bwd_a16_f32"}[op]
+if op.endswith("16"): arg = torch.empty((n, 512, 7, 7), dtype=torch.int16, device=dev)
 libs = []
 for path in sys.argv[1:]:
     lib = C.CDLL(os.path.abspath(path))
     fn = getattr(lib, sym)
     fn.restype, fn.argtypes = abi.SIGNATURES[sym]
     libs.append((path, fn))
-if op == "bwd":
+if op.startswith("bwd"):
     ops.roipool_forward(img, win, "max", out=out, argmax=arg, nhwc=nhwc, nan_flag=nanf)
     del nhwc
     gin = torch.empty((images, 512, 38, 50), device=dev)
     wsb = abi.load().dg_roipool_bwd_workspace_bytes(images, n)
     ws = torch.empty(wsb, dtype=torch.uint8, device=dev)
 def launch(fn):
-    if op == "fwd":
+    if op.startswith("fwd"):
         rc = fn(abi.ptr(nhwc), images, 512, 38, 50, abi.ptr(win), n, 7, abi.POOL_MAX, abi.ptr(nanf), abi.ptr(out), abi.ptr(arg), abi.stream_ptr(dev))
     else:
         rc = fn(abi.ptr(out), abi.ptr(arg), abi.ptr(win), n, images, 512, 38, 50, 7, abi.POOL_MAX, abi.ptr(gin), abi.ptr(ws), wsb, abi.stream_ptr(dev))
     assert rc == 0, rc
 ref = None
 for path, fn in libs:
-    if op == "fwd":
+    if op.startswith("fwd"):
         out.zero_(); arg.zero_(); launch(fn); torch.cuda.synchronize()
-        sig = (out.view(torch.int32).sum(dtype=torch.int64).item(), arg.sum(dtype=torch.int64).item())
+        sig = (out.view(torch.int32).sum(dtype=torch.int64).item(), arg.view(torch.uint16 if op == "fwd16" else torch.int32).sum(dtype=torch.int64).item())
     else:
         gin.zero_(); launch(fn); torch.cuda.synchronize()
         sig = (gin.double().sum().item(), gin.double().abs().sum().item())

@@ -17,6 +17,11 @@ template <bool NT> __global__ void k_linear(float *a, size_t n4)
     const v4f v = {1.f, 2.f, 3.f, (float)threadIdx.x};
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) st<NT>(a + 4 * i, v);
 }
+__global__ void k_two(float *a, float *b, size_t n4)
+{
+    const v4f v = {1.f, 2.f, 3.f, (float)threadIdx.x};
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) { st<false>(a + 4 * i, v); st<false>(b + 4 * i, v); }
+}
 template <bool NT> __global__ void k_linear_read(const float *a, size_t n4, float *sink)
 {
     v4f acc = {0.f, 0.f, 0.f, 0.f};
@@ -41,6 +46,22 @@ template <bool NT, int PAT> __global__ __launch_bounds__(64) void k_tasks(float 
         if (lane < 16) st<NT>(a + 12 * 256, v);
     }
 }
+// the uint16-argmax layout: 12.25 KB of values + 6.125 KB of indices per task
+template <bool NT> __global__ __launch_bounds__(64) void k_tasks16(float *out, float *arg16, long ntasks)
+{
+    const int lane = threadIdx.x;
+    const v4f v = {1.f, 2.f, 3.f, (float)lane};
+    for (long t = blockIdx.x; t < ntasks; t += gridDim.x) {
+        float *o = out + t * 3136 + lane * 4;
+        float *a = arg16 + t * 1568 + lane * 4;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) st<NT>(o + k * 256, v);
+        if (lane < 16) st<NT>(o + 12 * 256, v);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) st<NT>(a + k * 256, v);
+        if (lane < 8) st<NT>(a + 6 * 256, v);
+    }
+}
 int main(int argc, char **argv)
 {
     const long ntasks = 512000L * 8;                 // config 3: 256 images x 2000 RoIs x 8 channel blocks
@@ -48,6 +69,7 @@ int main(int argc, char **argv)
     float *buf;
     if (hipMalloc(&buf, 2 * half) != hipSuccess) { printf("alloc failed\n"); return 1; }
     float *out = buf, *arg = buf + half / 4;
+    double launch_bytes = 2.0 * half;
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     auto timeit = [&](const char *name, auto launch) {
         launch(); hipDeviceSynchronize();
@@ -56,7 +78,7 @@ int main(int argc, char **argv)
             hipEventRecord(e0); launch(); hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1); best = ms < best ? ms : best;
         }
-        printf("%-44s %8.3f ms  %6.2f TB/s\n", name, best, 2.0 * half / best / 1e9);
+        printf("%-52s %8.3f ms  %6.2f TB/s\n", name, best, launch_bytes / best / 1e9);
     };
     for (int blocks : {2048, 4096, 8192, 65536}) {
         char nm[96];
@@ -64,6 +86,31 @@ int main(int argc, char **argv)
         timeit(nm, [&] { k_linear<true><<<blocks, 256>>>(buf, 2 * half / 16); });
         snprintf(nm, sizeof nm, "linear plain, %d x 256 threads", blocks);
         timeit(nm, [&] { k_linear<false><<<blocks, 256>>>(buf, 2 * half / 16); });
+    }
+    if (argc > 1 && argv[1][0] == 'a') {
+        launch_bytes = 1.5 * half;
+        for (int waves : {2048, 4096}) {
+            char nm[96];
+            snprintf(nm, sizeof nm, "uint16-argmax pattern nt, %d waves", waves);
+            timeit(nm, [&] { k_tasks16<true><<<waves, 64>>>(out, arg, ntasks); });
+            snprintf(nm, sizeof nm, "uint16-argmax pattern plain, %d waves", waves);
+            timeit(nm, [&] { k_tasks16<false><<<waves, 64>>>(out, arg, ntasks); });
+        }
+        return 0;
+    }
+    if (argc > 1 && argv[1][0] == 's') {
+        // fill rate against the size of the region written (a fresh sub-range of the same allocation each time)
+        for (double gb : {1.0, 4.0, 12.85, 25.7, 51.4, 77.1, 102.8}) {
+            size_t n4 = (size_t)(gb * 1e9 / 16);
+            if (n4 > 2 * half / 16) n4 = 2 * half / 16;          // never past the allocation
+            char nm[96];
+            snprintf(nm, sizeof nm, "linear plain fill of %.1f GB", gb);
+            launch_bytes = n4 * 16.0;
+            timeit(nm, [&] { k_linear<false><<<2048, 256>>>(buf, n4); });
+            snprintf(nm, sizeof nm, "two streams (x and x + 51.4 GB), %.1f GB total", gb);
+            timeit(nm, [&] { k_two<<<2048, 256>>>(buf, buf + half / 4, n4 / 2); });
+        }
+        return 0;
     }
     if (argc > 1) {
         for (int blocks : {2048, 4096, 8192, 65536}) {

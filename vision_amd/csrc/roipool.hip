@@ -105,6 +105,8 @@ __device__ __forceinline__ void nt_store4(int32_t *p, int4 v)
 // v_max_f32 / v_max3_f32 as such: fmaxf would first canonicalise operands that come straight from memory
 __device__ __forceinline__ float vmaxf(float a, float b) { float o; asm("v_max_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b)); return o; }
 __device__ __forceinline__ float vmax3f(float a, float b, float c) { float o; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(o) : "v"(a), "v"(b), "v"(c)); return o; }
+// min against a wave-uniform limit (+inf keeps `a`, -inf resets it): a full-rate select with no VCC
+__device__ __forceinline__ float vmin_uniform(float a, float lim) { float o; asm("v_min_f32 %0, %1, %2" : "=v"(o) : "s"(lim), "v"(a)); return o; }
 
 #ifdef DG_STAMPS
 // diagnostic build only (tools/ubench/roi_fwd_stamps.hip): where a task spends its cycles
@@ -227,7 +229,12 @@ __device__ __forceinline__ void roi_task_staged(char *smem, const char *__restri
 // maximum wins, as in ATen.  The column is recovered once per bin at the end of the strip: the first pixel of
 // the winning row that equals the maximum (the row is still in the ring: the prefetch issued at the start of
 // the strip only overwrote rows above it).  The value written is that pixel's own bits (-0 stays -0).
-template <int LW>
+// SHARE: adjacent strips share their boundary row unless ph*Lh is a multiple of 7 (adaptive bins: floor / ceil edges), so
+// the per-bin maxima of the row scanned last seed the next strip as its row 0 and that row is not read again: Lh row
+// scans per task instead of up to Lh + 6.  Used by the uint16-argmax kernel, whose compute side is what bounds it (17.2 ->
+// 16.1 ms); the int32 kernel sits on the device's store rate and ran 2 % slower with it (20.3 -> 20.7 ms), so it keeps the
+// plain strips.
+template <int LW, bool SHARE>
 __device__ __forceinline__ void roi_task_exact(char *smem, const char *__restrict__ imgc0, int pixbytes, int W, int lane,
                                                int x1, int y1, int y2, int R, float (&oval)[RBINS], int (&oidx)[RBINS]
 #ifdef DG_STAMPS
@@ -260,6 +267,9 @@ __device__ __forceinline__ void roi_task_exact(char *smem, const char *__restric
     STAMP_ADD(0, tp0, tp1);
     const char *lbase = smem + lane * 4;
     int slot = 0, prev_hs = y1;
+    float rm[RP];                                          // per-bin maxima of the row scanned last (SHARE: live across strips)
+#pragma unroll
+    for (int i = 0; i < RP; ++i) rm[i] = -INFINITY;
 #pragma unroll
     for (int ph = 0; ph < RP; ++ph) {
         const int hs = y1 + (ph * Lh) / RP, he = y1 + ((ph + 1) * Lh + RP - 1) / RP;
@@ -274,24 +284,29 @@ __device__ __forceinline__ void roi_task_exact(char *smem, const char *__restric
         slot += hs - prev_hs;                              // hs advances by <= maxrows <= R
         if (slot >= R) slot -= R;
         prev_hs = hs;
+        // shared: this strip's first row is the previous strip's last one (wave-uniform); strip 0 never shares
+        const int shared = (SHARE && ph > 0 && ((ph * Lh) % RP) != 0) ? 1 : 0;
+        const float lim = shared ? INFINITY : -INFINITY;
         float best[RP];
         int brow[RP];
 #pragma unroll
-        for (int i = 0; i < RP; ++i) { best[i] = -INFINITY; brow[i] = 0; }
-        int sl = slot, so = slot * rowbytes;
-        for (int r = 0; r < he - hs; ++r) {
+        for (int i = 0; i < RP; ++i) { best[i] = (SHARE && ph > 0) ? vmin_uniform(rm[i], lim) : -INFINITY; brow[i] = 0; }
+        int sl = slot + shared;
+        if (SHARE && sl >= R) sl -= R;
+        int so = sl * rowbytes;
+        for (int r = shared; r < he - hs; ++r) {
             const char *rowp = lbase + so;
 #pragma unroll
             for (int i = 0; i < RP; ++i) {
                 const int s = (i * LW) / RP, w = ((i + 1) * LW + RP - 1) / RP - s;      // folded: i and LW are constants
-                float rm = *(const float *)(rowp + s * 256);
+                rm[i] = *(const float *)(rowp + s * 256);
                 int j = 1;
 #pragma unroll
                 for (; j + 1 < w; j += 2)
-                    rm = vmax3f(rm, *(const float *)(rowp + (s + j) * 256), *(const float *)(rowp + (s + j + 1) * 256));
-                if (j < w) rm = vmaxf(rm, *(const float *)(rowp + (s + j) * 256));
-                brow[i] = (rm > best[i]) ? r : brow[i];
-                best[i] = vmaxf(best[i], rm);
+                    rm[i] = vmax3f(rm[i], *(const float *)(rowp + (s + j) * 256), *(const float *)(rowp + (s + j + 1) * 256));
+                if (j < w) rm[i] = vmaxf(rm[i], *(const float *)(rowp + (s + j) * 256));
+                brow[i] = (rm[i] > best[i]) ? r : brow[i];
+                best[i] = vmaxf(best[i], rm[i]);
             }
             so += rowbytes;
             if (++sl == R) { sl = 0; so = 0; }
@@ -691,7 +706,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 #define STAMP_ARG
 #endif
                 const char *imgc0 = reinterpret_cast<const char *>(nhwc + ((int64_t)b * H * W) * C + c0);
-#define EXACT(LWV) case LWV: roi_task_exact<LWV>(smem, imgc0, C * 4, W, lane, x1, y1, y2, R, oval, oidx STAMP_ARG); break
+#define EXACT(LWV) case LWV: roi_task_exact<LWV, A16>(smem, imgc0, C * 4, W, lane, x1, y1, y2, R, oval, oidx STAMP_ARG); break
 #define STAGED(XWV) roi_task_staged<XWV, true>(smem, imgc0, C * 4, W, lane, x1, y1, x2, y2, R, oval, oidx STAMP_ARG)
                 if (!may_nan) {
                     switch (Lw) {
