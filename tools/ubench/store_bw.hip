@@ -17,6 +17,14 @@ template <bool NT> __global__ void k_linear(float *a, size_t n4)
     const v4f v = {1.f, 2.f, 3.f, (float)threadIdx.x};
     for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) st<NT>(a + 4 * i, v);
 }
+// torch-like shape: no grid stride, block b owns a contiguous 16 KB tile (4 x 16 B per thread, 4 KB apart)
+template <bool NT> __global__ void k_tiled(float *a, size_t n4)
+{
+    const v4f v = {1.f, 2.f, 3.f, (float)threadIdx.x};
+    const size_t base = (size_t)blockIdx.x * 1024 + threadIdx.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const size_t i = base + k * 256; if (i < n4) st<NT>(a + 4 * i, v); }
+}
 __global__ void k_two(float *a, float *b, size_t n4)
 {
     const v4f v = {1.f, 2.f, 3.f, (float)threadIdx.x};
@@ -98,9 +106,33 @@ int main(int argc, char **argv)
         }
         return 0;
     }
+    if (argc > 1 && argv[1][0] == 'g') {
+        // the forward's store pattern against the number of single-wave workgroups (tasks are block-strided)
+        for (int waves : {2048, 8192, 16384, 65536, 262144, 524288, 1048576, 4096000}) {
+            char nm[96];
+            snprintf(nm, sizeof nm, "forward pattern nt, %d workgroups", waves);
+            timeit(nm, [&] { k_tasks<true, 1><<<waves, 64>>>(out, arg, ntasks); });
+        }
+        return 0;
+    }
+    if (argc > 1 && argv[1][0] == 't') {
+        for (double gb : {4.0, 102.76, 4.0, 25.7, 102.76}) {
+            size_t n4 = (size_t)(gb * 1e9 / 16);
+            if (n4 > 2 * half / 16) n4 = 2 * half / 16;
+            launch_bytes = n4 * 16.0;
+            char nm[96];
+            snprintf(nm, sizeof nm, "tiled plain fill of %.1f GB", gb);
+            timeit(nm, [&] { k_tiled<false><<<(unsigned)((n4 + 1023) / 1024), 256>>>(buf, n4); });
+            snprintf(nm, sizeof nm, "tiled nt fill of %.1f GB", gb);
+            timeit(nm, [&] { k_tiled<true><<<(unsigned)((n4 + 1023) / 1024), 256>>>(buf, n4); });
+            snprintf(nm, sizeof nm, "grid-stride plain fill of %.1f GB", gb);
+            timeit(nm, [&] { k_linear<false><<<2048, 256>>>(buf, n4); });
+        }
+        return 0;
+    }
     if (argc > 1 && argv[1][0] == 's') {
         // fill rate against the size of the region written (a fresh sub-range of the same allocation each time)
-        for (double gb : {1.0, 4.0, 12.85, 25.7, 51.4, 77.1, 102.8}) {
+        for (double gb : {1.0, 4.0, 12.85, 25.7, 51.4, 77.1, 102.8, 77.1, 51.4, 25.7, 12.85, 4.0, 1.0, 4.0, 102.8}) {
             size_t n4 = (size_t)(gb * 1e9 / 16);
             if (n4 > 2 * half / 16) n4 = 2 * half / 16;          // never past the allocation
             char nm[96];

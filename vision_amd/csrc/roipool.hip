@@ -118,6 +118,7 @@ __device__ unsigned long long dg_stamp_acc[8];
 #define STAMP_ADD(slot, a, b)
 #endif
 
+#define FWD_TASKS_PER_WG 8               // large launches: block-strided tasks per single-wave workgroup (see roipool_fwd)
 #define RING_PX 64                       // crop pixels (x 64 channels x 4 B = 16 KiB) resident in LDS per wave
 #define FWD_LDS_FLOATS (64 * RBINS + 64 * RBINS / 2)   // [64][49] f32 values + [64][49] u16 indices = 18,816 B
 
@@ -1263,10 +1264,21 @@ static int roipool_fwd(const float *img_nhwc, int64_t B, int64_t C, int64_t H, i
     hipStream_t st = (hipStream_t)s;
     const int64_t cblocks = dg_cdiv(C, 64);
     const int64_t ntasks = n * cblocks;
-    const int64_t maxgrid = 256 * 8;                   // 256 CUs x 8 resident single-wave workgroups (18.8 KB LDS each)
-    dim3 grid((unsigned)(ntasks < maxgrid ? ntasks : maxgrid));
+    // 256 CUs x 8 single-wave workgroups (18.8 KB LDS each) are resident at a time.  Large launches do NOT use that many
+    // persistent workgroups: with about FWD_TASKS_PER_WG block-strided tasks per workgroup (grid a multiple of 8, so a
+    // workgroup still keeps one channel block and its XCD) the same kernel runs 13 % faster on config 3 (20.4 -> 17.6 ms;
+    // 2048 persistent waves 20.4, one task per workgroup 20.3, 8-16 tasks 17.6-17.8): waves of different ages share a
+    // SIMD, the older one is served first, and their compute and store phases stop running in lockstep.  Grids of
+    // 8k-32k workgroups are slower (23-25 ms: a workgroup's stride then equals one image and every wave walks across all
+    // maps at once).  DG_FWD_TPW overrides the tasks per workgroup (0 = the persistent grid), for experiments.
+    static const int tpw_env = getenv("DG_FWD_TPW") ? atoi(getenv("DG_FWD_TPW")) : FWD_TASKS_PER_WG;
+    const int64_t resident = 256 * 8;
+    int64_t ngrid = ntasks < resident ? ntasks : resident;
+    if (tpw_env > 0 && ntasks >= resident * 4 * tpw_env) ngrid = (ntasks / tpw_env + 7) & ~(int64_t)7;
+    dim3 grid((unsigned)ngrid);
+    dim3 grid_wide((unsigned)(ntasks < resident ? ntasks : resident));
 #define FWD_LAUNCH(MODE, A16, PART) \
-    hipLaunchKernelGGL((k_roipool_fwd<MODE, A16, PART>), grid, dim3(64), 0, st, img_nhwc, (int)C, (int)H, (int)W, win, (int)cblocks, ntasks, nan_flag, out, argmax, argmax16, vec_ok)
+    hipLaunchKernelGGL((k_roipool_fwd<MODE, A16, PART>), (PART == 0 ? grid : grid_wide), dim3(64), 0, st, img_nhwc, (int)C, (int)H, (int)W, win, (int)cblocks, ntasks, nan_flag, out, argmax, argmax16, vec_ok)
     // max mode: the main kernel, then the wide-crop kernel over the tasks the first one left (disjoint outputs)
     if (mode == DG_POOL_MAX && argmax16) { FWD_LAUNCH(DG_POOL_MAX, true, 0); if (DG_FWD_WIDE) FWD_LAUNCH(DG_POOL_MAX, true, 1); }
     else if (mode == DG_POOL_MAX) { FWD_LAUNCH(DG_POOL_MAX, false, 0); if (DG_FWD_WIDE) FWD_LAUNCH(DG_POOL_MAX, false, 1); }
