@@ -1266,11 +1266,14 @@ static int roipool_fwd(const float *img_nhwc, int64_t B, int64_t C, int64_t H, i
     const int64_t ntasks = n * cblocks;
     // 256 CUs x 8 single-wave workgroups (18.8 KB LDS each) are resident at a time.  Large launches do NOT use that many
     // persistent workgroups: with about FWD_TASKS_PER_WG block-strided tasks per workgroup (grid a multiple of 8, so a
-    // workgroup still keeps one channel block and its XCD) the same kernel runs 13 % faster on config 3 (20.4 -> 17.6 ms;
-    // 2048 persistent waves 20.4, one task per workgroup 20.3, 8-16 tasks 17.6-17.8): waves of different ages share a
-    // SIMD, the older one is served first, and their compute and store phases stop running in lockstep.  Grids of
-    // 8k-32k workgroups are slower (23-25 ms: a workgroup's stride then equals one image and every wave walks across all
-    // maps at once).  DG_FWD_TPW overrides the tasks per workgroup (0 = the persistent grid), for experiments.
+    // workgroup still keeps one channel block and its XCD) the same kernel runs 6-16 % faster on config 3, depending on
+    // the box (20.4 -> 17.1-17.6 ms, 18.5 -> 17.4 ms; 4 to 16 tasks per workgroup are alike, one task per workgroup is back
+    // at 20.3 ms: a workgroup start costs about as much as it saves).  What it buys is placement by the dispatcher -- a
+    // workgroup goes wherever a slot frees up -- instead of a fixed 1/2048 share of the tasks per wave; giving half of the
+    // persistent waves a higher s_setprio changed nothing, so it is not the age/priority order of the two waves of a SIMD.
+    // Grids of 8k-32k workgroups are slower (23-25 ms: a workgroup's stride then equals about one image, every wave
+    // walks across all maps and the XCD's L2 no longer holds the slices in use).
+    // DG_FWD_TPW overrides the tasks per workgroup (0 = the persistent grid), for experiments.
     static const int tpw_env = getenv("DG_FWD_TPW") ? atoi(getenv("DG_FWD_TPW")) : FWD_TASKS_PER_WG;
     const int64_t resident = 256 * 8;
     int64_t ngrid = ntasks < resident ? ntasks : resident;
