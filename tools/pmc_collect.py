@@ -58,6 +58,7 @@ traffic_path = os.path.join(OUT, "traffic.json")
 traffic = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
 traffic.setdefault("valu_insts_per_launch", {})
 traffic.setdefault(f"{TAG}_hbm_bytes_per_launch", {})
+seen_valu, seen_hbm = {}, {}
 with open(os.path.join(OUT, f"{TAG}_pmc_summary.csv"), "w") as fo:
     fo.write("workload,kernel,grid_threads,launches,avg_us,hbm_bytes,algorithmic_bytes,traffic_ratio,hbm_frac_of_8TBps,valu_lane_ops_frac,"
              "valu_per_unit,wait_any_share,wait_inst_share,active_share," + ",".join(cols) + "\n")
@@ -75,10 +76,13 @@ with open(os.path.join(OUT, f"{TAG}_pmc_summary.csv"), "w") as fo:
             f"{hbm / algo:.3f}" if (hbm and algo) else "", f"{algo / (us * 1e-6) / 8e12:.3f}" if algo else "",
             f"{valu * 64 / (us * 1e-6) / VALU_PEAK:.3f}" if valu else "", f"{valu * 64 / UNITS[wl]:.1f}" if valu else "",
             share("SQ_WAIT_ANY"), share("SQ_WAIT_INST_ANY"), share("SQ_ACTIVE_INST_ANY")] + [f"{d[c]:.6g}" if c in d else "" for c in cols]) + "\n")
+        # instantiations of one kernel that together serve a launch of the operator (k_roipool_fwd<.., 0> and <.., 1>) are summed
         if us > 5 and valu:
-            traffic["valu_insts_per_launch"].setdefault(base, {})[str(UNITS[wl])] = valu
+            seen_valu[(wl, base)] = seen_valu.get((wl, base), 0.0) + valu
+            traffic["valu_insts_per_launch"].setdefault(base, {})[str(UNITS[wl])] = seen_valu[(wl, base)]
         if hbm and algo:
-            traffic[f"{TAG}_hbm_bytes_per_launch"].setdefault(base, {})[str(UNITS[wl])] = {"hbm_bytes": hbm, "algorithmic_bytes": algo, "workload": wl}
+            seen_hbm[(wl, base)] = seen_hbm.get((wl, base), 0.0) + hbm
+            traffic[f"{TAG}_hbm_bytes_per_launch"].setdefault(base, {})[str(UNITS[wl])] = {"hbm_bytes": seen_hbm[(wl, base)], "algorithmic_bytes": algo, "workload": wl}
 fwd = traffic[f"{TAG}_hbm_bytes_per_launch"].get("k_roipool_fwd", {}).get("512000")
 if fwd:
     traffic.setdefault("k_roipool_fwd_bytes_per_launch", {})["512000"] = int(fwd["hbm_bytes"])
