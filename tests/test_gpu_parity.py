@@ -744,6 +744,25 @@ def test_roipool_uint16_argmax_equals_int32(va, C, n):
     assert torch.allclose(g32, g16, rtol=1e-4, atol=1e-3)                       # LDS accumulation order is not fixed
 
 
+@pytest.mark.parametrize("C,n", [(128, 33000), (64, 65537), (128, 32767)])
+def test_roipool_forward_launch_shapes_vs_oracle(va, oracle, C, n):
+    """task counts just above / below the point where the forward goes from 2048 persistent workgroups to about 8
+    block-strided tasks per workgroup (65536 tasks): every task still runs exactly once."""
+    from vision_amd import ops
+    rng = np.random.default_rng(C + n)
+    B, H, W = 3, 38, 50
+    img = rng.standard_normal((B, C, H, W), dtype=np.float32)
+    rois = np.concatenate([wl.frcnn_rois(5 + i, 2000) for i in range((n + 1999) // 2000)])[:n]
+    idx = rng.integers(0, B, n).astype(np.int64)
+    x = torch.from_numpy(img).cuda()
+    win, st = ops.roi_windows(rois, idx, B, H, W, x.device)
+    out = torch.full((n, C, 7, 7), float("nan"), device="cuda")
+    arg = torch.full((n, C, 7, 7), -1, dtype=torch.int32, device="cuda")
+    ops.roipool_forward(x, win, "max", out=out, argmax=arg)
+    want, warg = oracle.roipool_fwd(img, rois, idx, 7, "max")
+    assert np.array_equal(out.cpu().numpy(), want) and np.array_equal(arg.cpu().numpy(), warg)
+
+
 def test_roipool_uint16_argmax_every_width_and_height(va, oracle):
     """every crop width 1..24 x every crop height 1..38 through the uint16-argmax kernel (strip-sharing code: the cases differ
     by height mod 7) on a tie-rich map with both zeros, against the oracle."""
