@@ -28,6 +28,7 @@ extern "C" {
 #define DG_EEMPTYROI (-2) /* reported through the status word of dg_roi_windows */
 #define DG_ENOMEM (-3)    /* workspace too small */
 #define DG_EHIP (-4)      /* a HIP runtime call / launch failed */
+#define DG_ERCCL (-5)     /* RCCL could not be bound (librccl.so absent) or one of its calls failed */
 
 #define DG_POOL_AVG 0 /* rcnn/fast_rcnn.py:354 as written (AdaptiveAvgPool2d) */
 #define DG_POOL_MAX 1 /* north_star: max + argmax */
@@ -204,6 +205,38 @@ int dg_kmeans_finish(const int64_t *part, int64_t k, float *cent, int64_t *acc_o
 int dg_kmeans_iou_run(const float *wh, int64_t n, float *cent, int64_t k, uint8_t *labels, int64_t *acc,
                       int64_t *history, int64_t slot0, int64_t iters, void *ws, size_t ws_bytes, dg_stream_t s);
 int dg_kmeans_labels_i32(const uint8_t *labels, int64_t n, int32_t *out, dg_stream_t s);
+
+/* ---------------------------------------------------------------- the exchange step of the sharded k-means
+ * NO COUNTERPART IN THE REFERENCE (its KMeans is single-process sklearn, clustering/cluster_prac.py:38-40).  One process per
+ * GPU; the library issues RCCL's all-reduce itself, on the caller's stream, between its own launches.  RCCL is bound at
+ * run time (dlopen of librccl.so, the copy already in the process if there is one); without it these return DG_ERCCL and
+ * every other entry point is unaffected.
+ *  dg_comm_unique_id: rank 0 draws the 128-byte id (host memory) and hands it to the other ranks by any channel it has
+ *                     (vision_amd.cluster broadcasts it through torch.distributed);
+ *  dg_comm_init:      collective over the `nranks` callers, each with ITS device current; *out = the handle (host object,
+ *                     freed by dg_comm_destroy);
+ *  dg_comm_allreduce_i64: in-place SUM of buf[count] (device) over the ranks, asynchronous on stream s. */
+#define DG_COMM_ID_BYTES 128
+typedef struct dg_comm dg_comm_t;
+int dg_comm_unique_id(void *id_host);
+int dg_comm_init(dg_comm_t **out, const void *id_host, int rank, int nranks);
+int dg_comm_rank(const dg_comm_t *c);
+int dg_comm_size(const dg_comm_t *c);
+int dg_comm_allreduce_i64(dg_comm_t *c, int64_t *buf, int64_t count, dg_stream_t s);
+int dg_comm_destroy(dg_comm_t *c);
+/* dg_kmeans_iou_run over a SHARD of the boxes: `iters` iterations of [dg_kmeans_iou_iter; all-reduce of that launch's
+ * partial-sums buffer] and the finish, all issued by this one call on stream s (no host work between iterations).  Every
+ * rank calls it with its shard, the same cent / k / iters, and its own labels / acc / history / ws; results are
+ * bit-identical for every rank count (integer sums).  acc = the GLOBAL sums of the last iteration.
+ * use_graph != 0: the second call with the same arguments captures the chunk (launches + all-reduces) in a HIP graph
+ * (thread-local capture mode), later calls replay it -- one host launch per chunk; a capture failure falls back to
+ * eager issue for good (dg_last_error says why, the call still succeeds). */
+int dg_kmeans_iou_run_sharded(dg_comm_t *c, const float *wh, int64_t n, float *cent, int64_t k, uint8_t *labels,
+                              int64_t *acc, int64_t *history, int64_t slot0, int64_t iters, void *ws, size_t ws_bytes,
+                              int use_graph, dg_stream_t s);
+/* what use_graph has come to on this communicator: 0 nothing yet, 1 armed (the next call with the same arguments
+ * captures), 2 replaying a captured chunk, -1 capture failed (eager from then on) */
+int dg_comm_graph_state(const dg_comm_t *c);
 
 /* ---------------------------------------------------------------- R-CNN box regression ("next" rows)
  * calcul(positive,grt): rcnn/utils.py:153-171; inverse: rcnn/rcnn.py:287-310 (variant 0) and

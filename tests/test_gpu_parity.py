@@ -885,12 +885,13 @@ def test_kmeans_sharded_loop_single_rank_group_vs_oracle(va, oracle, graph, monk
     try:
         wh = wl.anchor_wh(5, 150001)
         x = torch.from_numpy(wh).cuda()
-        km = cluster.kmean(5, 42, sharded=True).fit(x)
+        km = cluster.kmean(5, 42, sharded=True, comm="torch").fit(x)
         cent, labels, n_iter, inertia = oracle.kmeans_fit(wh, 5, 42)
         assert np.array_equal(km.cluster_centers_, cent) and np.array_equal(km.labels_, labels)
         assert km.n_iter_ == n_iter and abs(km.inertia_ - inertia) < 1e-9
+        assert km.comm_state.startswith("torch")
         assert km.graph_state == ("captured" if graph == "1" else "eager: graph capture disabled or host-side all-reduce"), km.graph_state
-        km3 = cluster.kmean(5, 42, sharded=True).fit(x, fixed_iters=11)
+        km3 = cluster.kmean(5, 42, sharded=True, comm="torch").fit(x, fixed_iters=11)
         c3, l3, n3, i3 = oracle.kmeans_fit(wh, 5, 42, fixed_iters=11)
         assert np.array_equal(km3.cluster_centers_, c3) and np.array_equal(km3.labels_, l3) and km3.n_iter_ == 11
         km3._run_iters(0, 11)                     # replay (or eager re-run) continues the fit: 22 iterations
@@ -899,6 +900,58 @@ def test_kmeans_sharded_loop_single_rank_group_vs_oracle(va, oracle, graph, monk
         assert np.array_equal(km3._backend.cent.cpu().numpy(), c22)
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("graph", ["1", "0"])
+@pytest.mark.parametrize("with_group", [False, True])
+def test_kmeans_sharded_loop_library_comm_vs_oracle(va, oracle, graph, with_group, monkeypatch):
+    """The sharded loop issued by the library: dg_comm_* (RCCL bound inside libdetgeom.so, a single-rank communicator here:
+    one GPU) + dg_kmeans_iou_run_sharded -- eager first, captured in a HIP graph on the second run of a chunk, replayed
+    after -- to convergence and for fixed counts, against the oracle.  with_group: the id travels through torch.distributed."""
+    import socket
+    import torch.distributed as dist
+    from vision_amd import _abi, cluster
+    monkeypatch.setenv("DG_KMEANS_GRAPH", graph)
+    if with_group:
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+    try:
+        wh = wl.anchor_wh(6, 150001)
+        x = torch.from_numpy(wh).cuda()
+        km = cluster.kmean(5, 42, sharded=True).fit(x)                     # comm=None: the library's communicator
+        cent, labels, n_iter, inertia = oracle.kmeans_fit(wh, 5, 42)
+        assert km.comm_state == "so", km.comm_state
+        assert np.array_equal(km.cluster_centers_, cent) and np.array_equal(km.labels_, labels)
+        assert km.n_iter_ == n_iter and abs(km.inertia_ - inertia) < 1e-9
+        km.close()
+        km3 = cluster.kmean(5, 42, sharded=True, comm="so").fit(x, fixed_iters=11)           # first run of this chunk: eager
+        c3, l3, n3, i3 = oracle.kmeans_fit(wh, 5, 42, fixed_iters=11)
+        assert np.array_equal(km3.cluster_centers_, c3) and np.array_equal(km3.labels_, l3) and km3.n_iter_ == 11
+        assert abs(km3.inertia_ - i3) < 1e-9
+        assert km3.graph_state == ("armed" if graph == "1" else "eager: graph capture disabled"), km3.graph_state
+        for total in (22, 33):                    # second run captures and replays, third replays: the fit continues
+            km3._run_iters(0, 11)
+            torch.cuda.synchronize()
+            assert km3.graph_state == ("captured" if graph == "1" else "eager: graph capture disabled"), km3.graph_state
+            cN, _, _, _ = oracle.kmeans_fit(wh, 5, 42, fixed_iters=total)
+            assert np.array_equal(km3._backend.cent.cpu().numpy(), cN)
+        # on a user stream (capturable as it is) and through the bare all-reduce
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            km4 = cluster.kmean(5, 42, sharded=True, comm=km3._comm).fit(x, fixed_iters=3)
+            buf = torch.arange(40, dtype=torch.int64, device="cuda")
+            km3._comm.allreduce_i64(buf)
+        st.synchronize()
+        c4, l4, _, _ = oracle.kmeans_fit(wh, 5, 42, fixed_iters=3)
+        assert np.array_equal(km4.cluster_centers_, c4) and np.array_equal(km4.labels_, l4)
+        assert torch.equal(buf.cpu(), torch.arange(40))
+        km3.close()
+        with pytest.raises(ValueError):
+            _abi.check(_abi.load().dg_comm_allreduce_i64(None, None, 4, None))
+    finally:
+        if with_group:
+            dist.destroy_process_group()
 
 
 def _km_adversarial_boxes(seed, n, cent):

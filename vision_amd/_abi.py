@@ -13,7 +13,8 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdetgeom.so")
 
-OK, EINVAL, EEMPTYROI, ENOMEM, EHIP = 0, -1, -2, -3, -4
+OK, EINVAL, EEMPTYROI, ENOMEM, EHIP, ERCCL = 0, -1, -2, -3, -4, -5
+COMM_ID_BYTES = 128
 POOL_AVG, POOL_MAX = 0, 1
 
 _vp, _i64, _i32, _f32, _f64, _sz = C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_double, C.c_size_t
@@ -56,6 +57,14 @@ SIGNATURES = {
     "dg_kmeans_finish": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "dg_kmeans_iou_run": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _sz, _vp]),
     "dg_kmeans_labels_i32": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "dg_comm_unique_id": (C.c_int, [_vp]),
+    "dg_comm_init": (C.c_int, [C.POINTER(_vp), _vp, C.c_int, C.c_int]),
+    "dg_comm_rank": (C.c_int, [_vp]),
+    "dg_comm_size": (C.c_int, [_vp]),
+    "dg_comm_allreduce_i64": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "dg_comm_destroy": (C.c_int, [_vp]),
+    "dg_comm_graph_state": (C.c_int, [_vp]),
+    "dg_kmeans_iou_run_sharded": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _sz, C.c_int, _vp]),
     "dg_rcnn_calcul_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "dg_rcnn_decode_f32": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, _vp]),
     "dg_yolo1_encode_f64": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),

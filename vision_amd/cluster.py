@@ -5,9 +5,16 @@ The reference itself runs sklearn's Euclidean KMeans on a toy table; the 1-IoU L
 build-defined (spec: oracle/oracle.c) and therefore "parity unpinned".
 Multi-GPU: every rank holds a contiguous shard of the boxes; per iteration ONE launch (the centroid
 update is the prologue of the next step, dg_kmeans_iou_iter) and ONE all-reduce of the (3k+2) int64
-accumulator (RCCL over xGMI via torch.distributed); a chunk of iterations is captured in a HIP graph
-when the process group allows it.  Integer sums make the result bit-identical for every world size.
+accumulator over RCCL / xGMI.  Two ways to issue it:
+  comm="so"    (default on GPUs): the library owns an RCCL communicator (dg_comm_*) and
+               issues the whole chunk -- launches and all-reduces -- from one C call
+               (dg_kmeans_iou_run_sharded), captured in a HIP graph from its second run on;
+  comm="torch": launch + torch.distributed.all_reduce per iteration from Python, the chunk captured
+               with torch.cuda.graph when the process group allows it (and the gloo / host-side
+               rehearsal path, reduce_device="cpu").
+Integer sums make the result bit-identical for every world size and either way.
 """
+import ctypes as C
 import os
 
 import numpy as np
@@ -17,6 +24,49 @@ import torch.distributed as dist
 from . import _abi, ops
 
 _CHUNK = 8          # iterations launched between two host checks of the changed-count history
+
+
+class DgComm:
+    """RCCL communicator owned by libdetgeom.so (include/detgeom.h dg_comm_*): one per process and device."""
+
+    def __init__(self, handle, rank, world, device):
+        self.handle, self.rank, self.world, self.device = handle, rank, world, device
+
+    @classmethod
+    def create(cls, group=None, device=None):
+        """Collective over the ranks of `group` (torch.distributed carries the 128-byte id from rank 0 to the others);
+        without an initialised process group: a single-rank communicator."""
+        lib = _abi.load()
+        dev = device if device is not None else _abi.require_gpu()
+        have_pg = dist.is_available() and dist.is_initialized()
+        rank = dist.get_rank(group) if have_pg else 0
+        world = dist.get_world_size(group) if have_pg else 1
+        uid = C.create_string_buffer(_abi.COMM_ID_BYTES)
+        if rank == 0:
+            _abi.check(lib.dg_comm_unique_id(uid))
+        if world > 1:
+            box = [uid.raw]
+            src = dist.get_global_rank(group, 0) if group is not None else 0
+            with torch.cuda.device(dev):
+                dist.broadcast_object_list(box, src=src, group=group)
+            uid = C.create_string_buffer(box[0], _abi.COMM_ID_BYTES)
+        h = C.c_void_p()
+        with torch.cuda.device(dev):
+            _abi.check(lib.dg_comm_init(C.byref(h), uid, rank, world))
+        return cls(h, rank, world, dev)
+
+    def allreduce_i64(self, t):
+        assert t.dtype == torch.int64 and t.is_cuda and t.is_contiguous()
+        with torch.cuda.device(self.device):
+            _abi.check(_abi.load().dg_comm_allreduce_i64(self.handle, _abi.ptr(t), t.numel(), _abi.stream_ptr(self.device)))
+
+    def graph_state(self):
+        return _abi.load().dg_comm_graph_state(self.handle)
+
+    def close(self):
+        if self.handle is not None and self.handle.value:
+            h, self.handle = self.handle, None
+            _abi.check(_abi.load().dg_comm_destroy(h))
 
 
 class _HipBackend:
@@ -45,6 +95,15 @@ class _HipBackend:
             _abi.check(_abi.load().dg_kmeans_iou_run(_abi.ptr(self.wh), self.wh.shape[0], _abi.ptr(self.cent), self.cent.shape[0],
                                                      _abi.ptr(self.labels), _abi.ptr(self.acc), _abi.ptr(self.history), slot0, iters,
                                                      _abi.ptr(self.ws), self.ws_bytes, _abi.stream_ptr(dev)))
+
+    def run_sharded(self, comm, slot0, iters, use_graph):
+        """sharded, comm="so": `iters` x [launch; RCCL all-reduce] + finish issued by one C call (dg_kmeans_iou_run_sharded)"""
+        dev = self.wh.device
+        with torch.cuda.device(dev):
+            _abi.check(_abi.load().dg_kmeans_iou_run_sharded(comm.handle, _abi.ptr(self.wh), self.wh.shape[0], _abi.ptr(self.cent),
+                                                             self.cent.shape[0], _abi.ptr(self.labels), _abi.ptr(self.acc),
+                                                             _abi.ptr(self.history), slot0, iters, _abi.ptr(self.ws), self.ws_bytes,
+                                                             int(use_graph), _abi.stream_ptr(dev)))
 
     # The sharded loop issues one launch + one all-reduce per iteration from Python: with the kernel at a few microseconds
     # per shard the host side matters, so the ABI calls are bound once with raw pointers.
@@ -105,15 +164,22 @@ class _HipBackend:
 
 
 class kmean:
-    def __init__(self, n_clusters=5, random_state=42, max_iter=300, group=None, reduce_device=None, sharded=None):
+    def __init__(self, n_clusters=5, random_state=42, max_iter=300, group=None, reduce_device=None, sharded=None, comm=None):
         """sharded: None = the sharded loop iff the process group has more than one rank; True forces it (with a
-        single-rank group it then runs launch + all-reduce per iteration, which is how its device path is tested)."""
+        single-rank group it then runs launch + all-reduce per iteration, which is how its device path is tested).
+        comm: "so" = the library's own RCCL communicator and C-side loop, "torch" = torch.distributed.all_reduce from
+        Python, None = "so" unless the all-reduce runs on the host (reduce_device), the process group is not RCCL, or
+        DG_KMEANS_COMM=torch; a DgComm instance is used as it is (and stays the caller's to close)."""
         if not 1 <= n_clusters <= 16:
             raise ValueError("n_clusters must be in [1,16]")
         self.n_clusters, self.random_state, self.max_iter = n_clusters, random_state, max_iter
         self.group = group
         self.reduce_device = reduce_device      # all-reduce on another device (e.g. "cpu" with gloo)
         self.sharded = sharded
+        self.comm = comm
+        self._comm = comm if isinstance(comm, DgComm) else None
+        self.comm_state = "unused"              # "so" / "torch: <why>" once the sharded loop has run
+        self._side = None
         self._backend = _HipBackend()
         self._graphs = {}
         self.graph_state = "unused"             # "captured" / "eager: <why>" once the sharded loop has run
@@ -189,11 +255,69 @@ class kmean:
             self._allreduce(be.reduce_buffer())
         be.update(slot0 + count - 1)
 
+    def _so_comm(self):
+        """the library-side communicator for this fit, or None (then torch.distributed carries the all-reduce)"""
+        if self._comm is not None:
+            return self._comm
+        if self.comm_state.startswith("torch"):
+            return None
+        want = self.comm if self.comm is not None else os.environ.get("DG_KMEANS_COMM") or None
+        have_pg = dist.is_available() and dist.is_initialized()
+        if want == "torch" or self.reduce_device is not None or not self._backend.acc.is_cuda:
+            self.comm_state = "torch: asked for, or host-side all-reduce"
+            return None
+        if want is None and have_pg and dist.get_backend(self.group) != "nccl":
+            self.comm_state = "torch: process group is not RCCL"
+            return None
+        try:
+            self._comm = DgComm.create(self.group, self._backend.acc.device)
+            self._own_comm = True
+            self.comm_state = "so"
+        except Exception as e:  # noqa: BLE001  (librccl.so absent: symmetric on every rank)
+            if want == "so":
+                raise
+            self.comm_state = f"torch: dg_comm_init failed ({type(e).__name__}: {e})"
+        return self._comm
+
+    def close(self):
+        """frees the communicator this object created (collective: every rank calls it)"""
+        if getattr(self, "_own_comm", False) and self._comm is not None:
+            self._comm.close()
+            self._comm, self._own_comm = None, False
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def _run_so(self, comm, slot0, count):
+        be = self._backend
+        dev = be.wh.device
+        use_graph = os.environ.get("DG_KMEANS_GRAPH", "1") != "0"
+        cur = torch.cuda.current_stream(dev)
+        if use_graph and cur.cuda_stream == 0:
+            # the legacy default stream cannot be captured: the chunk runs on a side stream ordered after / before it
+            if self._side is None:
+                self._side = torch.cuda.Stream(dev)
+            self._side.wait_stream(cur)
+            with torch.cuda.stream(self._side):
+                be.run_sharded(comm, slot0, count, True)
+            cur.wait_stream(self._side)
+        else:
+            be.run_sharded(comm, slot0, count, use_graph)
+        st = comm.graph_state()
+        self.graph_state = {2: "captured", 1: "armed", 0: "eager: graph capture disabled"}.get(st, "eager: " + _abi.last_error())
+
     def _run_iters(self, slot0, count):
         """`count` Lloyd iterations, asynchronous on the current stream (history slots slot0..slot0+count-1)."""
         be = self._backend
         if not self._is_sharded():
             be.run_local(slot0, count)
+            return
+        comm = self._so_comm()
+        if comm is not None:
+            self._run_so(comm, slot0, count)
             return
         # HIP graph of the whole chunk (kernels + RCCL all-reduces): replays cost the host one launch.  Only when the
         # all-reduce runs on the device (not the gloo rehearsal path) and DG_KMEANS_GRAPH != 0; any capture failure

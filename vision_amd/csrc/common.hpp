@@ -23,6 +23,15 @@ void dg_set_error(const char *fmt, ...);
         if (e_ != hipSuccess) { dg_set_error("%s: launch failed: %s", name, hipGetErrorString(e_)); return DG_EHIP; } \
     } while (0)
 
+// communicator handle of include/detgeom.h (comm.hip owns it; kmeans.hip keeps the captured chunk of its sharded loop here)
+struct dg_comm {
+    void *comm = nullptr;            // ncclComm_t
+    int rank = 0, nranks = 1, device = 0;
+    void *graph_exec = nullptr;      // hipGraphExec_t of the last captured dg_kmeans_iou_run_sharded chunk
+    uint64_t graph_key[12] = {};     // the arguments it was captured with
+    int graph_state = 0;             // 0 none, 1 key seen once (ran eagerly), 2 captured, -1 capture failed: stay eager
+};
+
 static inline int64_t dg_cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 static inline int64_t dg_round_up(int64_t a, int64_t b) { return dg_cdiv(a, b) * b; }
 

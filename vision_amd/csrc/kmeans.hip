@@ -11,6 +11,7 @@
 // launch (+ one all-reduce of the replica buffer when the boxes are sharded over GPUs).
 #include "common.hpp"
 #include <stdlib.h>
+#include <string.h>
 
 #define KM_BLOCK 256
 #define KM_MAXBLOCKS 1024
@@ -553,6 +554,82 @@ extern "C" int dg_kmeans_iou_run(const float *wh, int64_t n, float *cent, int64_
     }
     return km_finish(part[(iters - 1) % 3], k, cent, acc, history, slot0 + iters - 1, st);
 }
+
+// ---- the sharded loop issued by the library: [launch; RCCL all-reduce of that launch's buffer] x iters; finish -------------
+static int km_sharded_issue(dg_comm_t *c, const float *wh, int64_t n, float *cent, int64_t k, uint8_t *labels, int64_t *acc,
+                            int64_t *history, int64_t slot0, int64_t iters, void *ws, hipStream_t st)
+{
+    const size_t pe = dg_kmeans_part_elems(k);
+    int64_t *part[3] = {(int64_t *)ws, (int64_t *)ws + pe, (int64_t *)ws + 2 * pe};
+    if (hipMemsetAsync(ws, 0, 3 * pe * 8, st) != hipSuccess) { dg_set_error("kmeans_run_sharded: memset failed"); return DG_EHIP; }
+    int rc;
+    for (int64_t t = 0; t < iters; ++t) {
+        // same rotation as dg_kmeans_iou_run; the buffer launch t added into is summed over the ranks before launch t+1 folds it
+        if ((rc = km_launch(wh, n, cent, k, labels, t ? part[(t - 1) % 3] : nullptr, part[t % 3], part[(t + 1) % 3], history,
+                            slot0 + t - 1, t + 1 == iters, st)))
+            return rc;
+        if ((rc = dg_comm_allreduce_i64(c, part[t % 3], (int64_t)pe, st))) return rc;
+    }
+    return km_finish(part[(iters - 1) % 3], k, cent, acc, history, slot0 + iters - 1, st);
+}
+
+extern "C" int dg_kmeans_iou_run_sharded(dg_comm_t *c, const float *wh, int64_t n, float *cent, int64_t k, uint8_t *labels,
+                                         int64_t *acc, int64_t *history, int64_t slot0, int64_t iters, void *ws, size_t ws_bytes,
+                                         int use_graph, dg_stream_t s)
+{
+    DG_REQUIRE(c, "kmeans_run_sharded: null communicator");
+    DG_REQUIRE(iters >= 0, "kmeans_run_sharded: iters < 0");
+    int rc = km_check("kmeans_run_sharded", wh, n, cent, k, labels);
+    if (rc) return rc;
+    DG_REQUIRE(acc, "kmeans_run_sharded: null acc");
+    if ((rc = km_check_ws("kmeans_run_sharded", n, k, ws, ws_bytes))) return rc;
+    if (iters == 0) return DG_OK;
+    hipStream_t st = (hipStream_t)s;
+    if (!use_graph || c->graph_state < 0) return km_sharded_issue(c, wh, n, cent, k, labels, acc, history, slot0, iters, ws, st);
+
+    const uint64_t key[12] = {(uint64_t)(uintptr_t)wh, (uint64_t)n, (uint64_t)(uintptr_t)cent, (uint64_t)k, (uint64_t)(uintptr_t)labels,
+                              (uint64_t)(uintptr_t)acc, (uint64_t)(uintptr_t)history, (uint64_t)slot0, (uint64_t)iters,
+                              (uint64_t)(uintptr_t)ws, (uint64_t)(uintptr_t)st, 0};
+    const bool same = c->graph_state > 0 && memcmp(key, c->graph_key, sizeof(key)) == 0;
+    if (same && c->graph_state == 2) {
+        if (hipGraphLaunch((hipGraphExec_t)c->graph_exec, st) != hipSuccess) { dg_set_error("kmeans_run_sharded: hipGraphLaunch failed"); return DG_EHIP; }
+        return DG_OK;
+    }
+    if (!same) {
+        // first call with these arguments: issued eagerly (RCCL sets up its channels on first use, outside any capture)
+        if (c->graph_exec) { (void)hipGraphExecDestroy((hipGraphExec_t)c->graph_exec); c->graph_exec = nullptr; }
+        memcpy(c->graph_key, key, sizeof(key));
+        c->graph_state = 1;
+        return km_sharded_issue(c, wh, n, cent, k, labels, acc, history, slot0, iters, ws, st);
+    }
+    // second call with the same arguments: capture the chunk, then replay it
+    hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        c->graph_state = -1;
+        dg_set_error("kmeans_run_sharded: stream capture refused (%s), issuing eagerly", hipGetErrorString(e));
+        return km_sharded_issue(c, wh, n, cent, k, labels, acc, history, slot0, iters, ws, st);
+    }
+    rc = km_sharded_issue(c, wh, n, cent, k, labels, acc, history, slot0, iters, ws, st);
+    hipGraph_t g = nullptr;
+    e = hipStreamEndCapture(st, &g);
+    hipGraphExec_t ex = nullptr;
+    if (rc == DG_OK && e == hipSuccess && g) e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
+    if (g) (void)hipGraphDestroy(g);
+    if (rc != DG_OK || e != hipSuccess || !ex) {
+        (void)hipGetLastError();
+        c->graph_state = -1;
+        if (rc == DG_OK) dg_set_error("kmeans_run_sharded: capture failed (%s), issuing eagerly", hipGetErrorString(e));
+        return km_sharded_issue(c, wh, n, cent, k, labels, acc, history, slot0, iters, ws, st);   // nothing ran during the capture
+    }
+    c->graph_exec = ex;
+    c->graph_state = 2;
+    if (hipGraphLaunch(ex, st) != hipSuccess) { dg_set_error("kmeans_run_sharded: hipGraphLaunch failed"); return DG_EHIP; }
+    return DG_OK;
+}
+
+// 0 none, 1 armed (next call with the same arguments captures), 2 replaying a captured chunk, -1 capture failed: eager for good
+extern "C" int dg_comm_graph_state(const dg_comm_t *c) { return c ? c->graph_state : 0; }
 
 extern "C" int dg_kmeans_labels_i32(const uint8_t *labels, int64_t n, int32_t *out, dg_stream_t s)
 {
