@@ -361,11 +361,14 @@ def extra_kmeans(d, n_total=10_000_000, iters=30):
         # first the loop issued eagerly (launch + RCCL all-reduce per iteration from Python): the number that exists even if
         # capturing RCCL into a HIP graph misbehaves on this node (the watchdog in main() then still has a k-means figure)
         os.environ["DG_KMEANS_GRAPH"] = "0"
-        ke = cluster.kmean(5, 42)
-        ke.fit(shard, init_centers=init, fixed_iters=iters)
-        sec_e = min(Dist.timed(d, lambda: ke._run_iters(0, iters), 1, 0) for _ in range(5))
-        eager = {"iters_per_s": iters / sec_e, "ms_per_iter": sec_e / iters * 1e3, "state": ke.graph_state}
-        PARTIAL["config4_kmeans_10M"] = {"eager_loop": eager, "ranks": d.world, "note": "graph-captured loop did not finish"}
+        eager = {}
+        for comm in ("torch", "so"):              # Python loop over torch.distributed, then the library's own C-side loop
+            ke = cluster.kmean(5, 42, comm=comm)
+            ke.fit(shard, init_centers=init, fixed_iters=iters)
+            sec_e = min(Dist.timed(d, lambda: ke._run_iters(0, iters), 1, 0) for _ in range(5))
+            eager[comm] = {"iters_per_s": iters / sec_e, "ms_per_iter": sec_e / iters * 1e3, "state": ke.graph_state, "comm": ke.comm_state}
+            PARTIAL["config4_kmeans_10M"] = {"eager_loop": dict(eager), "ranks": d.world, "note": "graph-captured loop did not finish"}
+            ke.close()
         os.environ["DG_KMEANS_GRAPH"] = "1"
         del ke
     km = cluster.kmean(5, 42, reduce_device="cpu" if d.rehearse else None)   # rehearsal: gloo reduces host tensors
@@ -375,11 +378,13 @@ def extra_kmeans(d, n_total=10_000_000, iters=30):
     ms = min(ev_time(lambda: km._run_iters(0, iters), 3, 1) for _ in range(3)) / iters
     r = {"iters_per_s": iters / sec, "ms_per_iter": sec / iters * 1e3, "boxes_total": n_total, "ranks": d.world,
          "sharded_loop": km.graph_state if d.world > 1 else "single device: dg_kmeans_iou_run",
+         "comm": km.comm_state if d.world > 1 else None,
          "device_ms_per_iter_this_shard": ms, "iter_hbm_frac": (12.0 * per) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
          "iter_valu_frac": valu_frac("k_kmeans_step", per, ms),
          "centers": km.cluster_centers_.round(6).tolist(), "eager_loop": eager,
          "note": "config 4, strong scaling: 10M boxes sharded; per iteration ONE launch (the centroid update is the prologue of "
-                 "the next step) + ONE 17 x int64 all-reduce, the 30 iterations replayed as one HIP graph when capture succeeds; "
+                 "the next step) + ONE all-reduce of the 2 KiB partial-sums buffer, issued by the library itself (dg_comm_* / "
+                 "dg_kmeans_iou_run_sharded; comm says which path ran), the 30 iterations replayed as one HIP graph when capture succeeds; "
                  "timed: best of 5 runs of 30 iterations, device-resident; the inertia sum is formed by the last iteration of a "
                  "run only, on one rank and on many alike; device_ms_per_iter = HIP-event time of the same 30 iterations / 30 "
                  "(k_kmeans_step is VALU-bound: iter_valu_frac = SQ_INSTS_VALU x 64 / time over the chip's 7.86e13 lane-ops/s)"}
@@ -389,13 +394,15 @@ def extra_kmeans(d, n_total=10_000_000, iters=30):
         try:
             dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{free_port()}", rank=0, world_size=1, device_id=d.dev)
             sub = torch.from_numpy(wh_all[:n_total // 8]).to(d.dev)
-            for mode in ("1", "0"):
-                os.environ["DG_KMEANS_GRAPH"] = mode
-                k8 = cluster.kmean(5, 42, sharded=True)
-                k8.fit(sub, init_centers=init, fixed_iters=iters)
-                s8 = min(Dist.timed(d, lambda: k8._run_iters(0, iters), 1, 0) for _ in range(5))
-                r["shard_1p25M_loop_graph" if mode == "1" else "shard_1p25M_loop_eager"] = {
-                    "us_per_iter": s8 / iters * 1e6, "state": k8.graph_state}
+            for comm in ("so", "torch"):           # the library's own communicator and C-side loop / torch.distributed from Python
+                for mode in ("1", "0"):
+                    os.environ["DG_KMEANS_GRAPH"] = mode
+                    k8 = cluster.kmean(5, 42, sharded=True, comm=comm)
+                    k8.fit(sub, init_centers=init, fixed_iters=iters)
+                    s8 = min(Dist.timed(d, lambda: k8._run_iters(0, iters), 1, 0) for _ in range(5))
+                    r["shard_1p25M_loop_%s_%s" % (comm, "graph" if mode == "1" else "eager")] = {
+                        "us_per_iter": s8 / iters * 1e6, "state": k8.graph_state, "comm": k8.comm_state}
+                    k8.close()
             os.environ["DG_KMEANS_GRAPH"] = "1"
             k1 = cluster.kmean(5, 42)                 # the same shard on the single-device loop: kernel time without a collective
             k1.sharded = False
