@@ -110,6 +110,17 @@ int dg_yolo1_decode_f32(const float *output, const float *target, int64_t batch,
                         float *out_box, int64_t *out_label, float *out_conf, float *out_score, int32_t *out_count,
                         double *tgt_box, int64_t *tgt_label, dg_stream_t s);
 
+/* decode -> nms as evaluate() chains them (yolo/yolo_v1/yolo.py:281-282), one launch for the whole batch: the candidates
+ * of an image stay in LDS between the two.  Outputs of dg_yolo1_decode_f32 as above, plus keep (batch,98) int64 / keep_count
+ * (batch) exactly as dg_nms_batched_f32 (per_class == 0: the reference's class-agnostic nms, :188-203) or
+ * dg_nms_batched_per_class_f32 (per_class != 0: BASELINE configs[1], no reference counterpart; class_count
+ * (batch,num_classes) int32 may be NULL) would give for (out_box, out_score[, out_label], out_count) at nms_threshold. */
+int dg_yolo1_decode_nms_f32(const float *output, const float *target, int64_t batch, int64_t num_classes,
+                            float conf_threshold, float prob_threshold, float nms_threshold, int per_class, int quirk_drop_last,
+                            float *out_box, int64_t *out_label, float *out_conf, float *out_score, int32_t *out_count,
+                            int64_t *keep, int32_t *keep_count, int32_t *class_count, double *tgt_box, int64_t *tgt_label,
+                            dg_stream_t s);
+
 /* ---------------------------------------------------------------- YOLOv2
  * get_point(output_size,bbox): yolo/yolo_v2/utils.py:228-234 (encoder, 13x13 hard-coded).
  * bbox: (n,4) xywh fp32 -> points (n,2) int64, enc (n,4) fp32 = [normed xy, wh]. */

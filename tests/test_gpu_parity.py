@@ -341,12 +341,14 @@ def test_ap_degenerate(va, oracle):
     assert np.array_equal(np.array(got), np.array(want), equal_nan=True), (got, want)
 
 
-def test_decode_nms_config2_vs_oracle(va, oracle):
-    """config 2 at full size (batch 64); ties between the two slots of a cell are ordered lower index first."""
+@pytest.mark.parametrize("fused", [True, False])
+def test_decode_nms_config2_vs_oracle(va, oracle, fused):
+    """config 2 at full size (batch 64); ties between the two slots of a cell are ordered lower index first.
+    fused: decode + NMS in one launch (dg_yolo1_decode_nms_f32) / the decode launch + the general batched NMS."""
     from vision_amd import yolo_v1
     out, tgt = wl.yolo1_batch(0, 64)
     box, label, conf, score, count, keep, kcnt, tbox, tlabel = [
-        t.cpu().numpy() for t in yolo_v1.decode_nms_batched(torch.from_numpy(out), torch.from_numpy(tgt), 0.2, 0.01, 0.3)]
+        t.cpu().numpy() for t in yolo_v1.decode_nms_batched(torch.from_numpy(out), torch.from_numpy(tgt), 0.2, 0.01, 0.3, fused=fused)]
     for i in range(64):
         b, l, c, s, tb, tl = oracle.yolo1_decode(out[i], tgt[i], 0.2, 0.01)
         assert count[i] == len(b) and np.array_equal(box[i, :count[i]], b) and np.array_equal(label[i, :count[i]], l)
@@ -367,14 +369,76 @@ def _nms_per_class_oracle(oracle, boxes, scores, labels, C, thr, quirk):
     return np.concatenate(keep) if keep else np.zeros(0, np.int64), per
 
 
-def test_decode_nms_config2_per_class_vs_oracle(va, oracle):
+@pytest.mark.parametrize("per_class", [False, True])
+@pytest.mark.parametrize("C", [5, 20, 1])
+def test_decode_nms_fused_equals_unfused_and_oracle(va, oracle, C, per_class):
+    """dg_yolo1_decode_nms_f32 (one launch, candidates in LDS) against the decode launch + the general batched NMS, bit for
+    bit, and against the oracle's decode + nms: thresholds that keep nothing / everything (98 candidates: both waves of
+    rows), thresholds sitting exactly on IoUs of the set and their float neighbours, 0, inf, NaN, both quirk settings, a
+    batch without targets, images with no / one / two candidates."""
+    from vision_amd import ops
+    rng = np.random.default_rng(100 + C + 7 * per_class)
+    B = 48
+    out = rng.random((B, 7, 7, 10 + C), dtype=np.float32)
+    out[..., 2:4] *= 0.6; out[..., 7:9] *= 0.6                       # sizes that overlap their neighbours
+    out[0] = 0.0                                                       # nothing passes
+    out[1] = 0.0; out[1, 3, 4, :] = 0.9                                # one cell: two candidates with equal scores
+    out[2] = 0.0; out[2, 0, 0, [0, 1, 2, 3, 4]] = 0.8; out[2, 0, 0, 10] = 0.7   # exactly one candidate
+    out[3, ..., 10:] = 0.95; out[3, ..., 4] = 1.0; out[3, ..., 9] = 1.0          # all 98 pass with equal scores
+    tgt = np.zeros_like(out)
+    for i in range(B):
+        tgt[i, rng.integers(0, 7), rng.integers(0, 7), :] = rng.random(10 + C, dtype=np.float32) + 0.1
+    # IoUs of image 5's candidates give thresholds that sit exactly on a quotient
+    b5, _, _, s5, _, _ = oracle.yolo1_decode(out[5], tgt[5], 0.2, 0.01)
+    ious = oracle.iou_pairwise(b5[:20], b5[:20], 1e-7).ravel()
+    ious = ious[(ious > 0.05) & (ious < 0.9)]
+    thrs = [0.3, 0.0, float("inf"), float("nan"), -1.0, 1e-30]
+    for q in ious[:4]:
+        thrs += [float(q), float(np.nextafter(np.float32(q), np.float32(0))), float(np.nextafter(np.float32(q), np.float32(1)))]
+    o, t = torch.from_numpy(out).cuda(), torch.from_numpy(tgt).cuda()
+    saw_full = False
+    for n_thr, thr in enumerate(thrs):
+        for quirk in (True, False):
+            for ct, pt in ((0.2, 0.01), (0.5, 0.3)):
+                tt = t if (n_thr % 2 == 0) else None
+                f = ops.yolo1_decode_batched(o, tt, ct, pt, thr, per_class, quirk)
+                box, label, conf, score, count, tbox, tlabel, keep, kcnt, ccnt = f
+                u = ops.yolo1_decode_batched(o, tt, ct, pt)
+                assert torch.equal(count, u[4])
+                cnt = count.cpu().numpy()
+                for a, b in zip(f[:4], u[:4]):                       # box, label, conf, score: the rows the decode wrote
+                    a, b = a.cpu().numpy(), b.cpu().numpy()
+                    assert all(np.array_equal(a[i, :cnt[i]], b[i, :cnt[i]]) for i in range(B))
+                if tt is not None:
+                    assert np.array_equal(tbox.cpu().numpy(), u[5].cpu().numpy(), equal_nan=True)
+                    assert torch.equal(tlabel, u[6])
+                if per_class:
+                    k2, c2, cc2, st = ops.nms_batched_per_class(u[0], u[3], u[1], C, u[4], thr, quirk)
+                    assert torch.equal(ccnt, cc2)
+                else:
+                    k2, c2 = ops.nms_batched(u[0], u[3], u[4], thr, quirk)
+                assert torch.equal(kcnt, c2), (thr, quirk)
+                keep, k2, kc = keep.cpu().numpy(), k2.cpu().numpy(), kcnt.cpu().numpy()
+                for i in range(B):
+                    assert np.array_equal(keep[i, :kc[i]], k2[i, :kc[i]]), (thr, quirk, i)
+                saw_full |= int(count.max()) == 98
+        if n_thr == 0 and not per_class:                               # and directly against the oracle
+            box, score, count = [x.cpu().numpy() for x in (f[0], f[3], f[4])]
+            for i in range(0, B, 5):
+                want = oracle.nms(box[i, :count[i]], score[i, :count[i]], thr, False)
+                assert kc[i] == len(want) and np.array_equal(keep[i, :kc[i]], want)
+    assert saw_full
+
+
+@pytest.mark.parametrize("fused", [True, False])
+def test_decode_nms_config2_per_class_vs_oracle(va, oracle, fused):
     """BASELINE configs[1] as worded: YOLOv1 decode + PER-CLASS NMS, batch 64.  Parity unpinned vs the reference (its nms is
     class-agnostic, yolo.py:282-298): checked against the oracle's nms applied per class.  Both box slots of a cell share the
     class score, so this input has tied keys by construction: ties are "lower index first" on both sides."""
     from vision_amd import yolo_v1
     out, tgt = wl.yolo1_batch(0, 64)
     box, label, conf, score, count, keep, kcnt, _, _ = yolo_v1.decode_nms_batched(torch.from_numpy(out).cuda(), torch.from_numpy(tgt).cuda(),
-                                                                                  0.2, 0.01, 0.3, per_class=True)
+                                                                                  0.2, 0.01, 0.3, per_class=True, fused=fused)
     box, label, score, count, keep, kcnt = [t.cpu().numpy() for t in (box, label, score, count, keep, kcnt)]
     assert count.max() > 60
     for i in range(64):

@@ -38,6 +38,8 @@ SIGNATURES = {
     "dg_nms_phase_mask": (C.c_int, [_vp, _i64, _i64, _f32, _vp, _sz, _vp]),
     "dg_nms_phase_reduce": (C.c_int, [_vp, _i64, _i64, C.c_int, _vp, _vp, _vp, _sz, _vp]),
     "dg_yolo1_decode_f32": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dg_yolo1_decode_nms_f32": (C.c_int, [_vp, _vp, _i64, _i64, _f32, _f32, _f32, C.c_int, C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                          _vp, _vp, _vp]),
     "dg_yolo2_get_point_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "dg_yolo2_decode_cells_f32": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "dg_yolo2_decode_anchor_f32": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp]),

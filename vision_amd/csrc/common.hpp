@@ -53,3 +53,34 @@ __device__ __forceinline__ float dg_iou(float ax1, float ay1, float ax2, float a
     float inter = ix * iy;
     return inter / (((aarea + barea) - inter) + eps);
 }
+
+// ---- device/host: pieces of the greedy NMS shared by nms.hip and the fused YOLOv1 decode + NMS kernel (decode.hip) -----
+// Order of yolo/yolo_v1/yolo.py:194 `sort(0, descending=True)`: descending score <=> ascending key; NaN sorts first (as
+// torch); ties -> lower index first (build-defined).  dg_score_desc() is the 32-bit score part of the key.
+__device__ __forceinline__ u32 dg_score_desc(float score)
+{
+    u32 u = __float_as_uint(score);
+    if (score != score) u = 0x7fffffffu;            // canonical +NaN: above +inf
+    u32 ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ~ord;
+}
+__device__ __forceinline__ u64 make_key(float score, u32 idx) { return ((u64)dg_score_desc(score) << 32) | idx; }
+
+// !(inter/den < thr) without the division (yolo.py:201 keeps iou < thr): with p the float below thr and mid = (p+thr)/2, a
+// correctly rounded quotient is < thr exactly when the real quotient is below mid (or equal to it when the tie rounds down
+// to p, i.e. thr's mantissa is odd).  mid has 25 significant bits and den 24: mid*den is exact in double, so is the compare.
+template <bool TIE_EVEN>
+__device__ __forceinline__ bool nms_suppressed(float inter, float den, double mid)
+{
+    const double prod = mid * (double)den, di = (double)inter;
+    return TIE_EVEN ? !(di < prod) : !(di <= prod);
+}
+// host: *mid for a threshold; returns TIE_EVEN (thr's mantissa even: a quotient exactly on mid rounds up to thr)
+static inline bool dg_nms_threshold_mid(float threshold, double *mid)
+{
+    if (threshold != threshold) *mid = (double)threshold;
+    else *mid = ((double)__builtin_nextafterf(threshold, -__builtin_inff()) + (double)threshold) * 0.5;
+    uint32_t tbits;
+    __builtin_memcpy(&tbits, &threshold, 4);
+    return (tbits & 1u) == 0;
+}

@@ -19,19 +19,23 @@ __device__ __forceinline__ void y1_box(const float *o, int cx, int cy, double *b
     b[0] = x - hw; b[1] = y - hh; b[2] = x + hw; b[3] = y + hh;
 }
 
-__global__ __launch_bounds__(64) void k_yolo1_decode(const float *__restrict__ output, const float *__restrict__ target,
-                                                     int C, float ct, float pt,
-                                                     float *__restrict__ out_box, int64_t *__restrict__ out_label,
-                                                     float *__restrict__ out_conf, float *__restrict__ out_score,
-                                                     int32_t *__restrict__ out_count,
-                                                     double *__restrict__ tgt_box, int64_t *__restrict__ tgt_label)
+// Candidates of one image as the NMS of the fused kernel wants them (LDS): list order = the reference's (:164-178).
+#define Y1_MAXCAND 128            // 2 * Y1_CELLS = 98, padded to two waves
+struct Y1Cand {
+    float4 box[Y1_MAXCAND];
+    float score[Y1_MAXCAND];
+    int label[Y1_MAXCAND];
+    int count;
+};
+
+// The decode of one image, cells = lanes of ONE wave (`lane` 0..63), from the prediction staged in LDS (`so`).  Writes the
+// image's rows of the global outputs and, when `cand` is given, the same candidates into LDS.
+__device__ __forceinline__ void y1_cells(const float *so, int lane, int img, int C, float ct, float pt,
+                                         float *__restrict__ out_box, int64_t *__restrict__ out_label,
+                                         float *__restrict__ out_conf, float *__restrict__ out_score,
+                                         int32_t *__restrict__ out_count, Y1Cand *cand)
 {
-    __shared__ float so[Y1_CELLS * Y1_MAXCH];
-    const int img = blockIdx.x, lane = threadIdx.x;
-    const int N = 10 + C, total = Y1_CELLS * N;
-    const float *g = output + (int64_t)img * total;
-    for (int t = lane; t < total; t += 64) so[t] = g[t];
-    __syncthreads();
+    const int N = 10 + C;
     const bool active = lane < Y1_CELLS;
     const int cell = active ? lane : 0;
     const int cy = cell / Y1_S, cx = cell % Y1_S;
@@ -61,33 +65,228 @@ __global__ __launch_bounds__(64) void k_yolo1_decode(const float *__restrict__ o
                 out_label[ob + pos] = cl;
                 out_conf[ob + pos] = slot == 0 ? conf1 : conf2;
                 out_score[ob + pos] = cs;
+                if (cand) { cand->box[pos] = f; cand->score[pos] = cs; cand->label[pos] = cl; }
             }
         }
     }
-    if (lane == 0) out_count[img] = c1 + __builtin_popcountll(b2);
+    if (lane == 0) {
+        out_count[img] = c1 + __builtin_popcountll(b2);
+        if (cand) cand->count = c1 + __builtin_popcountll(b2);
+    }
+}
 
-    if (target) {                                    // :121,:133-134,:140-152
+// The ground-truth cell of one image (:121,:133-134,:140-152) by ONE wave, from the target staged in LDS (`st`).
+__device__ __forceinline__ void y1_target(const float *st, int lane, int img, int C, double *__restrict__ tgt_box,
+                                          int64_t *__restrict__ tgt_label)
+{
+    const int N = 10 + C;
+    const bool active = lane < Y1_CELLS;
+    const int cell = active ? lane : 0;
+    const int cy = cell / Y1_S, cx = cell % Y1_S;
+    const float *o = st + cell * N;
+    float sum = 0.f;
+    for (int c = 0; c < N; ++c) sum += o[c];
+    const u64 objm = __ballot(active && sum != 0.f);
+    if (objm == 0) {
+        if (lane == 0) {
+            tgt_label[img] = 0;
+            for (int k = 0; k < 4; ++k) tgt_box[4 * img + k] = __longlong_as_double(0x7ff8000000000000LL);
+        }
+    } else if (lane == __builtin_ctzll(objm)) {
+        int best = 0;
+        for (int c = 1; c < C; ++c) if (o[10 + c] >= o[10 + best]) best = c;
+        tgt_label[img] = best + 1;
+        double bx[4];
+        y1_box(o, cx, cy, bx);
+        for (int k = 0; k < 4; ++k) tgt_box[4 * img + k] = bx[k];
+    }
+}
+
+__global__ __launch_bounds__(64) void k_yolo1_decode(const float *__restrict__ output, const float *__restrict__ target,
+                                                     int C, float ct, float pt,
+                                                     float *__restrict__ out_box, int64_t *__restrict__ out_label,
+                                                     float *__restrict__ out_conf, float *__restrict__ out_score,
+                                                     int32_t *__restrict__ out_count,
+                                                     double *__restrict__ tgt_box, int64_t *__restrict__ tgt_label)
+{
+    __shared__ float so[Y1_CELLS * Y1_MAXCH];
+    const int img = blockIdx.x, lane = threadIdx.x;
+    const int total = Y1_CELLS * (10 + C);
+    const float *g = output + (int64_t)img * total;
+    for (int t = lane; t < total; t += 64) so[t] = g[t];
+    __syncthreads();
+    y1_cells(so, lane, img, C, ct, pt, out_box, out_label, out_conf, out_score, out_count, nullptr);
+    if (target) {
         __syncthreads();
         const float *tg = target + (int64_t)img * total;
         for (int t = lane; t < total; t += 64) so[t] = tg[t];
         __syncthreads();
-        float sum = 0.f;
-        for (int c = 0; c < N; ++c) sum += o[c];
-        const u64 objm = __ballot(active && sum != 0.f);
-        if (objm == 0) {
-            if (lane == 0) {
-                tgt_label[img] = 0;
-                for (int k = 0; k < 4; ++k) tgt_box[4 * img + k] = __longlong_as_double(0x7ff8000000000000LL);
+        y1_target(so, lane, img, C, tgt_box, tgt_label);
+    }
+}
+
+// ---------------------------------------------------------------- decode -> nms of evaluate(), yolo/yolo_v1/yolo.py:281-282, one launch
+// One 512-thread workgroup per image; the image's <= 98 candidates never leave LDS between the decode and the NMS
+// (config 2 as four launches -- decode, sort, mask, reduce -- is launch-latency-bound: 50 us per batch of 64).
+//   decode: wave 0 = the 49 cells of the prediction, wave 1 = the ground-truth cell of the target, at the same time;
+//   sort:   thread t ranks candidate t by counting smaller keys (key = class | descending score | list index; class = 0
+//           unless per_class, so the order is k_nms_sort_small's);
+//   mask:   the M(M-1)/2 pairs j > i dealt evenly to all threads, the EXACT test of k_nms_mask (nms_suppressed, no
+//           division); per_class: only boxes of one class suppress each other; bits set by LDS atomics;
+//   reduce: wave 0, rows in registers (lane l: rows l and l+64), the serial chain reads them with v_readlane; a class run
+//           is a segment: the `numel()>1` quirk (the candidate left alone is dropped, :196) is applied per segment;
+//   keep:   kept positions -> list indices by popcount prefix; per_class: class order, then score (dg_nms_batched_per_class_f32).
+__device__ __forceinline__ void bits128_range(int a, int b, u64 &lo, u64 &hi)      // bits [a,b) of a 128-bit word
+{
+    auto below = [](int n) -> u64 { return n <= 0 ? 0ull : (n >= 64 ? ~0ull : ((1ull << n) - 1ull)); };
+    lo = below(b) & ~below(a);
+    hi = below(b - 64) & ~below(a - 64);
+}
+
+__device__ __forceinline__ u64 y1_readlane64(u64 v, int l)      // the builtin returns a signed int: widen through u32
+{
+    const u32 lo = __builtin_amdgcn_readlane((u32)v, l), hi = __builtin_amdgcn_readlane((u32)(v >> 32), l);
+    return ((u64)hi << 32) | lo;
+}
+
+#define Y1_FUSED_T 512
+template <bool TIE_EVEN>
+__global__ __launch_bounds__(Y1_FUSED_T) void k_yolo1_decode_nms(const float *__restrict__ output, const float *__restrict__ target,
+                                                                 int C, float ct, float pt, double mid, int per_class, int quirk,
+                                                                 float *__restrict__ out_box, int64_t *__restrict__ out_label,
+                                                                 float *__restrict__ out_conf, float *__restrict__ out_score,
+                                                                 int32_t *__restrict__ out_count, int64_t *__restrict__ keep,
+                                                                 int32_t *__restrict__ keep_count, int32_t *__restrict__ class_count,
+                                                                 double *__restrict__ tgt_box, int64_t *__restrict__ tgt_label)
+{
+    __shared__ float so[Y1_CELLS * Y1_MAXCH], st[Y1_CELLS * Y1_MAXCH];
+    __shared__ Y1Cand cand;
+    __shared__ u64 ckey[Y1_MAXCAND];
+    __shared__ float4 sbox[Y1_MAXCAND];
+    __shared__ float sarea[Y1_MAXCAND];
+    __shared__ int sorder[Y1_MAXCAND], slabel[Y1_MAXCAND];
+    __shared__ u64 rowlo[Y1_MAXCAND], rowhi[Y1_MAXCAND];
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    {   // prediction and target staged together; wave 0 decodes the cells while wave 1 finds the ground-truth cell
+        const int total = Y1_CELLS * (10 + C);
+        const float *g = output + (int64_t)img * total;
+        for (int t = tid; t < total; t += Y1_FUSED_T) so[t] = g[t];
+        if (target) {
+            const float *tg = target + (int64_t)img * total;
+            for (int t = tid; t < total; t += Y1_FUSED_T) st[t] = tg[t];
+        }
+        __syncthreads();
+        if (tid < 64) y1_cells(so, lane, img, C, ct, pt, out_box, out_label, out_conf, out_score, out_count, &cand);
+        else if (tid < 128 && target) y1_target(st, lane, img, C, tgt_box, tgt_label);
+    }
+    if (class_count && tid < C) class_count[(int64_t)img * C + tid] = 0;
+    __syncthreads();
+    const int M = cand.count, Mr = (M + 7) & ~7;                     // M <= 98, Mr <= 104: inside the padded arrays
+
+    // ---- sort by rank counting (keys past M are ~0: never below a live key)
+    u64 mykey = ~0ull;
+    if (tid < M) mykey = ((u64)(per_class ? cand.label[tid] : 0) << 40) | ((u64)dg_score_desc(cand.score[tid]) << 8) | (u64)tid;
+    if (tid < Y1_MAXCAND) { ckey[tid] = mykey; rowlo[tid] = 0ull; rowhi[tid] = 0ull; }
+    __syncthreads();
+    if (tid < M) {
+        int rank = 0;
+        for (int j = 0; j < Mr; j += 8) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) rank += ckey[j + u] < mykey;
+        }
+        const float4 b = cand.box[tid];
+        sbox[rank] = b;
+        sarea[rank] = dg_area(b.x, b.y, b.z, b.w);
+        sorder[rank] = tid;
+        slabel[rank] = cand.label[tid];
+    }
+    __syncthreads();
+
+    // ---- suppression rows (bit j of row i, j > i).  A lone wave issues an instruction every ~5 cycles, so the M(M-1)/2
+    // pairs are dealt evenly to all 512 threads: group g = rows g and M-1-g (M-1 pairs between them), 8 threads per group;
+    // suppressed pairs (few) set their bit with an LDS atomic.
+    {
+        const int g = tid >> 3, q = tid & 7;
+        const int A = g, B = M - 1 - g;
+        if (A <= B) {
+            const int nA = M - 1 - A, L = nA + (B != A ? g : 0);
+            const float4 boxA = sbox[A], boxB = sbox[B];
+            const float areaA = sarea[A], areaB = sarea[B];
+            const int labA = slabel[A], labB = slabel[B];
+            for (int e = q; e < L; e += 8) {
+                const bool inA = e < nA;
+                const int i = inA ? A : B, j = inA ? A + 1 + e : B + 1 + (e - nA);
+                const float4 p = inA ? boxA : boxB, c = sbox[j];
+                const float ix = fmaxf(fminf(p.z, c.z) - fmaxf(p.x, c.x), 0.0f);
+                const float iy = fmaxf(fminf(p.w, c.w) - fmaxf(p.y, c.y), 0.0f);
+                const float inter = ix * iy;
+                const float den = (((inA ? areaA : areaB) + sarea[j]) - inter) + 1e-7f;
+                bool sup = nms_suppressed<TIE_EVEN>(inter, den, mid);
+                if (per_class) sup = sup && (slabel[j] == (inA ? labA : labB));
+                if (sup) atomicOr((unsigned long long *)(j < 64 ? &rowlo[i] : &rowhi[i]), 1ull << (j & 63));
             }
-        } else if (lane == __builtin_ctzll(objm)) {
-            int best = 0;
-            for (int c = 1; c < C; ++c) if (o[10 + c] >= o[10 + best]) best = c;
-            tgt_label[img] = best + 1;
-            double bx[4];
-            y1_box(o, cx, cy, bx);
-            for (int k = 0; k < 4; ++k) tgt_box[4 * img + k] = bx[k];
         }
     }
+    __syncthreads();
+    if (tid >= 64) return;
+
+    // ---- serial chain (wave 0): rows in registers (lane l: rows l and l+64), read with v_readlane; the chain hops from
+    // one kept box to the next alive one (ctz), first through positions 0..63, then 64..127, inside one segment at a time
+    const u64 r0lo = rowlo[tid], r0hi = rowhi[tid], r1hi = rowhi[tid + 64];      // rows >= 64 have no bits below 64
+    // per_class: position i starts a class run when its label differs from position i-1's
+    u64 startlo = per_class ? __ballot(tid > 0 && tid < M && slabel[tid] != slabel[tid - 1]) : 0ull;
+    u64 starthi = per_class ? __ballot(tid + 64 < M && slabel[tid + 64] != slabel[tid + 63]) : 0ull;
+    u64 remlo = 0, remhi = 0, keptlo = 0, kepthi = 0;
+    int s0 = 0;
+    while (s0 < M) {
+        // segment [s0, e0): up to the next class start (class-agnostic: everything)
+        int e0 = M;
+        if (startlo) e0 = __builtin_ctzll(startlo);
+        else if (starthi) e0 = 64 + __builtin_ctzll(starthi);
+        if (e0 < 64) startlo &= startlo - 1; else if (e0 < M) starthi &= starthi - 1;
+        u64 mlo, mhi;
+        bits128_range(s0, e0, mlo, mhi);
+        u64 blo = 0, bhi = 0;
+        int last = -1, total = 0;
+        u64 alive = ~remlo & mlo;
+        while (alive) {
+            const int r = __builtin_ctzll(alive);
+            keptlo |= 1ull << r;
+            blo = remlo; bhi = remhi; last = r; total += 1;
+            remlo |= y1_readlane64(r0lo, r);
+            remhi |= y1_readlane64(r0hi, r);
+            alive = ~remlo & mlo & ~((2ull << r) - 1ull);
+        }
+        alive = ~remhi & mhi;
+        while (alive) {
+            const int r = __builtin_ctzll(alive);
+            kepthi |= 1ull << r;
+            blo = remlo; bhi = remhi; last = 64 + r; total += 1;
+            remhi |= y1_readlane64(r1hi, r);
+            alive = ~remhi & mhi & ~((2ull << r) - 1ull);
+        }
+        if (quirk && last >= 0) {
+            // yolo.py:196 `while ids_sorted.numel()>1`: the segment's last kept box is dropped iff nothing ranked below it
+            // (in its segment) was still alive when it became the head, i.e. before its own row was applied
+            u64 alo, ahi;
+            bits128_range(last + 1, e0, alo, ahi);
+            if (((~blo & alo) | (~bhi & ahi)) == 0ull) {
+                if (last < 64) keptlo &= ~(1ull << last);
+                else kepthi &= ~(1ull << (last - 64));
+                total -= 1;
+            }
+        }
+        if (class_count && per_class && tid == 0 && total > 0) class_count[(int64_t)img * C + slabel[s0]] = total;
+        s0 = e0;
+    }
+
+    // ---- keep list: sorted position -> index in the image's candidate list
+    int64_t *kp = keep + (int64_t)img * (2 * Y1_CELLS);
+    const u64 below = (1ull << tid) - 1ull;
+    const int nlo = __builtin_popcountll(keptlo);
+    if ((keptlo >> tid) & 1ull) kp[__builtin_popcountll(keptlo & below)] = (int64_t)sorder[tid];
+    if ((kepthi >> tid) & 1ull) kp[nlo + __builtin_popcountll(kepthi & below)] = (int64_t)sorder[tid + 64];
+    if (tid == 0) keep_count[img] = nlo + __builtin_popcountll(kepthi);
 }
 
 extern "C" int dg_yolo1_decode_f32(const float *output, const float *target, int64_t batch, int64_t num_classes,
@@ -104,6 +303,33 @@ extern "C" int dg_yolo1_decode_f32(const float *output, const float *target, int
     hipLaunchKernelGGL(k_yolo1_decode, dim3((unsigned)batch), dim3(64), 0, (hipStream_t)s, output, target, (int)num_classes,
                        conf_threshold, prob_threshold, out_box, out_label, out_conf, out_score, out_count, tgt_box, tgt_label);
     DG_CHECK_LAUNCH("k_yolo1_decode");
+    return DG_OK;
+}
+
+extern "C" int dg_yolo1_decode_nms_f32(const float *output, const float *target, int64_t batch, int64_t num_classes,
+                                       float conf_threshold, float prob_threshold, float nms_threshold, int per_class,
+                                       int quirk_drop_last, float *out_box, int64_t *out_label, float *out_conf, float *out_score,
+                                       int32_t *out_count, int64_t *keep, int32_t *keep_count, int32_t *class_count,
+                                       double *tgt_box, int64_t *tgt_label, dg_stream_t s)
+{
+    DG_REQUIRE(batch >= 0, "yolo1_decode_nms: batch < 0");
+    if (batch == 0) return DG_OK;
+    DG_REQUIRE(num_classes >= 1 && 10 + num_classes <= Y1_MAXCH, "yolo1_decode_nms: num_classes must be in [1,%d]", Y1_MAXCH - 10);
+    DG_REQUIRE(output && out_box && out_label && out_conf && out_score && out_count && keep && keep_count,
+               "yolo1_decode_nms: null pointer");
+    DG_REQUIRE(!target || (tgt_box && tgt_label), "yolo1_decode_nms: target given without tgt outputs");
+    DG_REQUIRE((((uintptr_t)out_box) & 15) == 0, "yolo1_decode_nms: out_box must be 16-byte aligned");
+    double mid;
+    const bool tie_even = dg_nms_threshold_mid(nms_threshold, &mid);
+    if (tie_even)
+        hipLaunchKernelGGL(k_yolo1_decode_nms<true>, dim3((unsigned)batch), dim3(Y1_FUSED_T), 0, (hipStream_t)s, output, target,
+                           (int)num_classes, conf_threshold, prob_threshold, mid, per_class != 0, quirk_drop_last != 0, out_box,
+                           out_label, out_conf, out_score, out_count, keep, keep_count, class_count, tgt_box, tgt_label);
+    else
+        hipLaunchKernelGGL(k_yolo1_decode_nms<false>, dim3((unsigned)batch), dim3(Y1_FUSED_T), 0, (hipStream_t)s, output, target,
+                           (int)num_classes, conf_threshold, prob_threshold, mid, per_class != 0, quirk_drop_last != 0, out_box,
+                           out_label, out_conf, out_score, out_count, keep, keep_count, class_count, tgt_box, tgt_label);
+    DG_CHECK_LAUNCH("k_yolo1_decode_nms");
     return DG_OK;
 }
 

@@ -65,15 +65,7 @@ static NmsWs nms_layout(int64_t batch, int64_t nmax, void *base)
     return w;
 }
 
-// descending score <=> ascending key; ties -> lower index first; NaN sorts first (as torch)
-__device__ __forceinline__ u64 make_key(float score, u32 idx)
-{
-    u32 u = __float_as_uint(score);
-    if (score != score) u = 0x7fffffffu;            // canonical +NaN: above +inf
-    u32 ord = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-    return ((u64)(~ord) << 32) | idx;
-}
-
+// make_key (descending score <=> ascending key; ties -> lower index first; NaN first, as torch): common.hpp
 __device__ __forceinline__ void gather_sorted(const float4 *__restrict__ boxes, u64 key, bool valid, int64_t p,
                                               float *x1, float *y1, float *x2, float *y2, float *area, int32_t *order)
 {
@@ -190,12 +182,7 @@ __global__ __launch_bounds__(256) void k_nms_gather(const float4 *__restrict__ b
 // Besides the mask words, every row gets a summary: bit w of rsum[row][t] says word 64t+w is non-zero.
 // The reduce phase walks summaries, so it touches only the non-zero words of the rows it keeps.
 #define MT_WORDS 64
-template <bool TIE_EVEN>
-__device__ __forceinline__ bool nms_suppressed(float inter, float den, double mid)
-{
-    const double prod = mid * (double)den, di = (double)inter;
-    return TIE_EVEN ? !(di < prod) : !(di <= prod);
-}
+// nms_suppressed<TIE_EVEN>(inter, den, mid): common.hpp
 
 // v_min/v_max as such: fminf/fmaxf would first canonicalise every operand (one more VALU op each); with
 // quiet NaNs the result is the same, the non-NaN operand
@@ -904,14 +891,11 @@ extern "C" int dg_nms_phase_mask(const int32_t *counts, int64_t batch, int64_t n
     if (rc || batch == 0 || nmax == 0) return rc;
     // midpoint between thr and the float below it, and which way a quotient exactly on it rounds (see k_nms_mask)
     double mid;
-    if (threshold != threshold) mid = (double)threshold;
-    else mid = ((double)nextafterf(threshold, -INFINITY) + (double)threshold) * 0.5;
-    uint32_t tbits;
-    memcpy(&tbits, &threshold, 4);
+    const bool tie_even = dg_nms_threshold_mid(threshold, &mid);
     const int fast_ok = threshold >= 0x1p-20f && threshold < INFINITY;
     const float below = fast_ok ? nextafterf(threshold, -INFINITY) : threshold;
     dim3 grid((unsigned)dg_cdiv(w.W, MT_WORDS), (unsigned)w.W, (unsigned)batch);
-    if ((tbits & 1u) == 0)
+    if (tie_even)
         hipLaunchKernelGGL(k_nms_mask<true>, grid, dim3(256), 0, (hipStream_t)s, w.x1, w.y1, w.x2, w.y2, w.area, counts, nmax, w.Np,
                            w.W, w.SW, threshold, below, mid, fast_ok, w.mask, w.rsum);
     else

@@ -100,7 +100,10 @@ def nms_batched_per_class(boxes, scores, labels, num_classes, counts=None, thres
 
 
 # ------------------------------------------------------------------ YOLOv1 decode
-def yolo1_decode_batched(output, target=None, conf_threshold=0.2, prob_threshold=0.1):
+def yolo1_decode_batched(output, target=None, conf_threshold=0.2, prob_threshold=0.1, nms_threshold=None, per_class=False,
+                         quirk_drop_last=True):
+    """decode of a batch; with nms_threshold the NMS runs in the same launch (dg_yolo1_decode_nms_f32) and the result
+    gains (keep (B,98) int64, keep_count (B) int32, class_count (B,C) int32)."""
     dev = _abi.device_of(output, target)
     o = _f32c(output, dev)
     if o.dim() == 3:
@@ -119,6 +122,16 @@ def yolo1_decode_batched(output, target=None, conf_threshold=0.2, prob_threshold
     count = torch.empty((B,), dtype=torch.int32, device=dev)
     tbox = torch.empty((B, 4), dtype=torch.float64, device=dev) if t is not None else None
     tlabel = torch.empty((B,), dtype=torch.int64, device=dev) if t is not None else None
+    if nms_threshold is not None:
+        keep = torch.empty((B, 98), dtype=torch.int64, device=dev)
+        kcnt = torch.empty((B,), dtype=torch.int32, device=dev)
+        ccnt = torch.empty((B, C_), dtype=torch.int32, device=dev) if per_class else None
+        with torch.cuda.device(dev):
+            check(load().dg_yolo1_decode_nms_f32(ptr(o), ptr(t), B, C_, float(conf_threshold), float(prob_threshold),
+                                                 float(nms_threshold), int(bool(per_class)), int(bool(quirk_drop_last)), ptr(box),
+                                                 ptr(label), ptr(conf), ptr(score), ptr(count), ptr(keep), ptr(kcnt), ptr(ccnt),
+                                                 ptr(tbox), ptr(tlabel), stream_ptr(dev)))
+        return box, label, conf, score, count, tbox, tlabel, keep, kcnt, ccnt
     with torch.cuda.device(dev):
         check(load().dg_yolo1_decode_f32(ptr(o), ptr(t), B, C_, float(conf_threshold), float(prob_threshold), ptr(box), ptr(label),
                                          ptr(conf), ptr(score), ptr(count), ptr(tbox), ptr(tlabel), stream_ptr(dev)))

@@ -114,12 +114,18 @@ def nms(out_box, out_score, threshold=0.1):
     return _back(keep[0, :k], dev_in)
 
 
-def decode_nms_batched(output, target=None, conf_threshold=0.2, prob_threshold=0.1, nms_threshold=0.3, per_class=False):
-    """Fused path for a whole batch (config 2): decode -> batched NMS with no host round trip in between.
+def decode_nms_batched(output, target=None, conf_threshold=0.2, prob_threshold=0.1, nms_threshold=0.3, per_class=False,
+                       fused=True):
+    """Fused path for a whole batch (config 2): decode -> NMS in ONE launch (the image's candidates stay in LDS;
+    fused=False: the decode launch followed by the general batched NMS -- same results, four launches).
     Returns device tensors (box, label, conf, score, count, keep, keep_count, tbox, tlabel).
     per_class=False is the reference (class-agnostic NMS per image, yolo.py:282; the split by class comes after it,
     :289-298).  per_class=True is BASELINE.json configs[1] as worded -- the same nms applied to each class's boxes
     separately; keep then lists the classes' survivors in class order (no reference counterpart)."""
+    if fused:
+        box, label, conf, score, count, tbox, tlabel, keep, kcnt, _ = ops.yolo1_decode_batched(
+            output, target, conf_threshold, prob_threshold, nms_threshold, per_class, True)
+        return box, label, conf, score, count, keep, kcnt, tbox, tlabel
     box, label, conf, score, count, tbox, tlabel = ops.yolo1_decode_batched(output, target, conf_threshold, prob_threshold)
     if per_class:
         keep, kcnt, _, _ = ops.nms_batched_per_class(box, score, label, torch.as_tensor(output).shape[-1] - 10, count,
