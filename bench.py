@@ -311,7 +311,11 @@ def extra_yolo(d):
                                                p(count), p(keep), p(kcnt), p(ccnt), p(tbox), p(tlabel), st))
     us_raw = min(ev_time(lambda: raw(0), 200, 20) for _ in range(3)) * 1e3
     us_raw_pc = min(ev_time(lambda: raw(1), 200, 20) for _ in range(3)) * 1e3
-    r = {"decode_nms_b64_ms": ms, "launch_only_us": us_raw, "boxes_per_s": 64 * 98 / ms * 1e3, "launches": 1,
+    gr = yolo_v1.DecodeNmsGraph(64, 5, 0.2, 0.01, 0.3, device=d.dev)
+    gr.output.copy_(o); gr.target.copy_(t)
+    us_graph = min(ev_time(gr, 200, 20) for _ in range(3)) * 1e3
+    r = {"decode_nms_b64_ms": ms, "launch_only_us": us_raw, "graph_replay_us": us_graph,
+         "graph_replay_boxes_per_s": 64 * 98 / us_graph * 1e6, "boxes_per_s": 64 * 98 / ms * 1e3, "launches": 1,
          "decode_nms_b64_unfused_ms": ms_unfused, "unfused_launches": 4,
          "decode_nms_b4096_ms": ms_big, "b4096_boxes_per_s": 4096 * 98 / ms_big * 1e3,
          "loss_fwd_bwd_b64_ms": ms_loss, "loss_cells_per_s": 64 * 49 / ms_loss * 1e3,

@@ -369,6 +369,22 @@ def _nms_per_class_oracle(oracle, boxes, scores, labels, C, thr, quirk):
     return np.concatenate(keep) if keep else np.zeros(0, np.int64), per
 
 
+def test_decode_nms_graph_replay(va, oracle):
+    """DecodeNmsGraph: the fused launch captured once, replayed on new inputs written into its static buffers."""
+    from vision_amd import yolo_v1
+    gr = yolo_v1.DecodeNmsGraph(16, 5, 0.2, 0.01, 0.3)
+    for seed in (3, 4):
+        out, tgt = wl.yolo1_batch(seed, 16)
+        gr.output.copy_(torch.from_numpy(out)); gr.target.copy_(torch.from_numpy(tgt))
+        got = [x.cpu().numpy() for x in gr()]
+        want = [x.cpu().numpy() for x in yolo_v1.decode_nms_batched(torch.from_numpy(out).cuda(), torch.from_numpy(tgt).cuda(), 0.2, 0.01, 0.3, fused=False)]
+        cnt, kc = want[4], want[6]
+        assert np.array_equal(got[4], cnt) and np.array_equal(got[6], kc)
+        for i in range(16):
+            assert np.array_equal(got[0][i, :cnt[i]], want[0][i, :cnt[i]]) and np.array_equal(got[5][i, :kc[i]], want[5][i, :kc[i]])
+        assert np.array_equal(got[7], want[7]) and np.array_equal(got[8], want[8])
+
+
 @pytest.mark.parametrize("per_class", [False, True])
 @pytest.mark.parametrize("C", [5, 20, 1])
 def test_decode_nms_fused_equals_unfused_and_oracle(va, oracle, C, per_class):

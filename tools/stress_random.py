@@ -95,6 +95,26 @@ for it in range(rounds):
     ol, ocomp, ograd = oracle.yolo1_loss(out, tgt, quirk=True)
     loss6, grad = ops.yolo1_loss(torch.from_numpy(out).cuda(), torch.from_numpy(tgt).cuda(), True)
     chk("loss", abs(loss6[0].item() - ol) <= 3e-7 * abs(ol) and np.allclose(grad.cpu().numpy(), ograd, rtol=3e-6, atol=1e-7), (bs, Cn))
+    # ---- fused YOLOv1 decode + NMS (one launch) against the oracle's decode followed by its nms (class-agnostic / per class)
+    thr1 = float(rng.choice([0.05, 0.3, 0.5, 0.9])); q1 = bool(rng.integers(2)); pc = bool(rng.integers(2))
+    ct, pt = float(rng.choice([0.2, 0.5, 0.9])), float(rng.choice([0.01, 0.1, 0.4]))
+    if rng.random() < 0.5: out = rng.random(out.shape, dtype=np.float32)            # dense candidates (up to 98 per image)
+    f = ops.yolo1_decode_batched(torch.from_numpy(out).cuda(), torch.from_numpy(tgt).cuda(), ct, pt, thr1, pc, q1)
+    fb, fl, fs, fc, fk, fkc = [f[i].cpu().numpy() for i in (0, 1, 3, 4, 7, 8)]
+    for i in range(bs):
+        b_, l_, c_, s_, tb_, tl_ = oracle.yolo1_decode(out[i], tgt[i], ct, pt)
+        ok = fc[i] == len(b_) and (len(b_) == 0 or (np.array_equal(fb[i, :fc[i]], b_) and np.array_equal(fl[i, :fc[i]], l_)))
+        if ok and len(b_):
+            b_, l_, s_ = np.asarray(b_, np.float32), np.asarray(l_), np.asarray(s_, np.float32)
+            if pc:
+                wk = [ii[oracle.nms(b_[ii], s_[ii], thr1, q1)] for ii in (np.flatnonzero(l_ == c) for c in range(Cn)) if ii.size]
+                wk = np.concatenate(wk) if wk else np.zeros(0, np.int64)
+            else:
+                wk = oracle.nms(b_, s_, thr1, q1)
+            ok = fkc[i] == len(wk) and np.array_equal(fk[i, :fkc[i]], wk)
+        elif ok:
+            ok = fkc[i] == 0
+        chk("fused decode+nms", ok, (bs, Cn, i, thr1, q1, pc, ct, pt))
     # ---- VOC AP: random detections / targets, thresholds incl. one that sits exactly on an occurring IoU
     import tests.test_gpu_parity as T
     from vision_amd import yolo_v1

@@ -135,6 +135,35 @@ def decode_nms_batched(output, target=None, conf_threshold=0.2, prob_threshold=0
     return box, label, conf, score, count, keep, kcnt, tbox, tlabel
 
 
+class DecodeNmsGraph:
+    """decode -> NMS of a fixed-shape batch as ONE HIP-graph replay (serving / evaluation loops: the launch is a few
+    microseconds of kernel time, so a Python call per batch -- ten output allocations and a ctypes call -- costs more
+    than the work).  The caller writes predictions into `.output` (and `.target`), calls the object, and reads the
+    results from the same tensors every time: (box, label, conf, score, count, keep, keep_count, tbox, tlabel), as
+    decode_nms_batched returns them.  Results are overwritten by the next call."""
+
+    def __init__(self, batch, num_classes=5, conf_threshold=0.2, prob_threshold=0.1, nms_threshold=0.3, per_class=False,
+                 with_target=True, device=None):
+        from . import _abi
+        dev = torch.device(device) if device is not None else _abi.require_gpu()
+        self.output = torch.zeros((batch, 7, 7, 10 + num_classes), dtype=torch.float32, device=dev)
+        self.target = torch.zeros_like(self.output) if with_target else None
+        args = (self.output, self.target, conf_threshold, prob_threshold, nms_threshold, per_class)
+        side = torch.cuda.Stream(dev)                     # capture needs a non-default stream; warm up on it first
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            decode_nms_batched(*args)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=side):
+            self.results = decode_nms_batched(*args)
+
+    def __call__(self):
+        self.graph.replay()
+        return self.results
+
+
 def evaluate_batch(output, target, num_classes=5, prob_threshold=0.005, nms_threshold=0.3, detects=None, targets=None):
     """yolo.py:273-299 minus the model call: `output` is the (B,7,7,10+C) prediction.  Appends rows
     [img, conf, x1,y1,x2,y2] to detects[c] and [img, 1, x1,y1,x2,y2] to targets[label-1]."""
