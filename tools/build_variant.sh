@@ -4,7 +4,7 @@
 set -e
 name=$1; src=$2; var=$(realpath "$3")
 cd "$(dirname "$0")/../vision_amd/csrc"
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -Wno-unused-function"
+FLAGS="$EXTRA_FLAGS -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -Wno-unused-function"
 cp "$var" /tmp/variant_$name.hip
 /opt/rocm/bin/hipcc $FLAGS -I. -c -x hip /tmp/variant_$name.hip -o /tmp/variant_$name.o
 objs=""

@@ -166,8 +166,9 @@ __global__ __launch_bounds__(256) void k_nms_gather(const float4 *__restrict__ b
 }
 
 // ---------------------------------------------------------------- mask
-// grid: x = column tile (64 words = 4096 columns), y = 64-row block, z = image.  256 threads; a wave
-// owns 16 of the tile's 64 word-columns.  One lane owns one column; the row box is an LDS broadcast.
+// grid: x = column tile (MT_WORDS = 32 words = 2048 columns), y = 64-row block, z = image.  256 threads; a wave
+// owns 8 of the tile's 32 word-columns (32-word tiles: 17 KB of LDS, eight workgroups = 8 waves per SIMD on a CU;
+// with 64-word tiles and four workgroups per CU the 64k mask took 1.31 ms instead of 1.20).  One lane owns one column; the row box is an LDS broadcast.
 //
 // The test !(inter/den < thr) is done without the division.  With p = the float below thr and
 // m = (p+thr)/2, a correctly rounded quotient is < thr exactly when the real quotient is below m
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) void k_nms_gather(const float4 *__restrict__ b
 //
 // Besides the mask words, every row gets a summary: bit w of rsum[row][t] says word 64t+w is non-zero.
 // The reduce phase walks summaries, so it touches only the non-zero words of the rows it keeps.
-#define MT_WORDS 64
+#define MT_WORDS 32
 // nms_suppressed<TIE_EVEN>(inter, den, mid): common.hpp
 
 // v_min/v_max as such: fminf/fmaxf would first canonicalise every operand (one more VALU op each); with
@@ -190,7 +191,7 @@ __device__ __forceinline__ float vmin(float a, float b) { float o; asm("v_min_f3
 __device__ __forceinline__ float vmax(float a, float b) { float o; asm("v_max_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b)); return o; }
 
 template <bool TIE_EVEN>
-__global__ __launch_bounds__(256, 2) void k_nms_mask(const float *__restrict__ sx1, const float *__restrict__ sy1,
+__global__ __launch_bounds__(256, 4) void k_nms_mask(const float *__restrict__ sx1, const float *__restrict__ sy1,
                                                   const float *__restrict__ sx2, const float *__restrict__ sy2,
                                                   const float *__restrict__ sarea, const int32_t *__restrict__ counts,
                                                   int64_t nmax, int64_t Np, int64_t W, int64_t SW, float thr, float thr_below,
@@ -263,18 +264,23 @@ __global__ __launch_bounds__(256, 2) void k_nms_mask(const float *__restrict__ s
     }
     __syncthreads();
     if (tid < 64) {
-        u64 sbits = 0;
+        u32 sbits = 0;
 #pragma unroll 8
-        for (int w = 0; w < MT_WORDS; ++w) sbits |= (u64)(tile[tid][w] != 0ull) << w;
-        rsum[(o + (int64_t)ib * 64 + tid) * SW + jt] = sbits;
+        for (int w = 0; w < MT_WORDS; ++w) sbits |= (u32)(tile[tid][w] != 0ull) << w;
+        // half of the row's summary word (little endian: tile jt even = low half); the even tile writes the whole word
+        // when the odd one has no columns (it returns at the top, or is not in the grid)
+        const int64_t si = (o + (int64_t)ib * 64 + tid) * SW;
+        if ((jt & 1) == 0 && (int64_t)(jb0 + MT_WORDS) * 64 >= n) rsum[si + (jt >> 1)] = (u64)sbits;
+        else reinterpret_cast<u32 *>(rsum)[si * 2 + jt] = sbits;
     }
-    // 64 rows x 64 words out, 512 contiguous bytes per row
+    // 64 rows x 32 words out, 256 contiguous bytes per row, two rows per wave pass
     u64 *mo = mask + (o + (int64_t)ib * 64) * W + jb0;
-    if (jb0 + lane < W) {
+    const int col = lane & 31, half = lane >> 5;
+    if (jb0 + col < W) {
 #pragma unroll 4
-        for (int p = 0; p < 16; ++p) {
-            const int row = wave + 4 * p;
-            mo[(int64_t)row * W + lane] = tile[row][lane];
+        for (int p = 0; p < 8; ++p) {
+            const int row = (wave + 4 * p) * 2 + half;
+            mo[(int64_t)row * W + col] = tile[row][col];
         }
     }
 }
