@@ -88,6 +88,27 @@ def test_nms_large_vs_oracle(va, oracle, n, dense, thr):
     assert np.array_equal(keep.cpu().numpy(), oracle.nms(b, s, thr)), (n, dense, thr)
 
 
+@pytest.mark.parametrize("dense", [False, True])
+def test_nms_band_reduce_forced_vs_oracle(va, oracle, dense, monkeypatch):
+    """k_nms_reduce_band (the reduce of images whose compact mask form overflows) on every kind of input: with
+    DG_NMS_FORCE_FALLBACK=1 no image "fits" the compact form, so sparse and dense, ragged, single-block and multi-super-block
+    images all go through it; both quirk settings; against the oracle."""
+    from vision_amd import ops
+    monkeypatch.setenv("DG_NMS_FORCE_FALLBACK", "1")
+    for n, thr in ((449, 0.5), (513, 0.3), (1100, 0.7), (4097, 0.5), (9000, 0.3), (20000, 0.6)):
+        B = 3
+        counts = np.array([n, max(n - 70, 1), min(450, n - 1)], np.int32)
+        boxes = np.zeros((B, n, 4), np.float32); scores = np.zeros((B, n), np.float32)
+        for i in range(B):
+            boxes[i], scores[i] = wl.stress_boxes(1000 + n + i, n, dense=dense)
+        for quirk in (True, False):
+            keep, cnt = ops.nms_batched(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), torch.from_numpy(counts), thr, quirk)
+            keep, cnt = keep.cpu().numpy(), cnt.cpu().numpy()
+            for i in range(B):
+                want = oracle.nms(boxes[i, :counts[i]], scores[i, :counts[i]], thr, quirk)
+                assert cnt[i] == len(want) and np.array_equal(keep[i, :cnt[i]], want), (n, thr, quirk, i)
+
+
 def test_nms_threshold_edges_vs_oracle(va, oracle):
     """The mask phase tests inter/den < thr without dividing: thresholds that are exactly an IoU value of the set,
     its float neighbours, 0, negatives, inf and NaN must all give the oracle's (dividing) answer."""

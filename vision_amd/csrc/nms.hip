@@ -390,144 +390,161 @@ __global__ __launch_bounds__(T) void k_nms_reduce(const u64 *__restrict__ mask, 
     if (tid == 0) keep_count[img] = total;
 }
 
-// Reduce for long segments (W > 64): `removed` lives in LDS and only the non-zero words of kept rows are
-// fetched, found through the row summaries.  Every wave resolves the diagonal word itself (rows whose
-// diagonal word is zero cannot suppress anything, so the serial chain only visits the others), then
-// the kept rows are dealt round-robin to the waves and OR-ed in with LDS atomics: one barrier per block.
-// removed1 lags removed2 by the most recent block's last kept row, so at the end it holds the state
-// "before the last kept box was applied" that the numel()>1 quirk asks about.
-template <int T>
-__global__ __launch_bounds__(T) void k_nms_reduce_sum(const u64 *__restrict__ mask, const u64 *__restrict__ rsum,
-                                                      const int32_t *__restrict__ order, const int32_t *__restrict__ counts,
-                                                      int64_t nmax, int64_t Np, int64_t W, int64_t SW, int quirk,
-                                                      int64_t *__restrict__ keep, int32_t *__restrict__ keep_count,
-                                                      const int32_t *__restrict__ cflag)
+// ---------------------------------------------------------------- reduce for DENSE masks (8 <= W <= 1024, compact form overflowed)
+// Round 1's kernel here (k_nms_reduce_sum: row summaries, only the non-zero words of kept rows) paid one HBM round trip
+// per 64-row block: the words of the rows it keeps can be fetched only once the block is resolved (2.43 ms for 64k dense
+// boxes at thr 0.5; this kernel 1.17 ms).  But the next blocks need only the NEAR words of those rows.  So the chain runs over SUPER-BLOCKS of
+// 8 blocks (512 rows):
+//   band:    the 512 x 8 words [rows of the super-block] x [its own 8 word columns] depend on nothing: they are fetched a
+//            super-block ahead (4 words per thread in registers) and live in LDS (32 KB);
+//   phase 1: wave 0 alone resolves the 8 blocks from the band -- diagonal word by v_readlane chain as in the other
+//            reduces, the kept rows' near words (inside the super-block) OR-ed into `removed` with LDS atomics, which one
+//            wave sees in order: no barrier inside a super-block;
+//   phase 2: every thread owns one word column w: it ORs word w of ALL rows the super-block kept into removed[w] -- the
+//            loads of a super-block are independent, one HBM round trip per 512 rows instead of one per 64.
+// removed1 lags by the last kept row of the latest super-block that kept anything (`pend`): it ends as "everything but the
+// last kept box", which is what the numel()>1 quirk asks about (yolo.py:196).
+#define BAND_BLOCKS 8
+__global__ __launch_bounds__(1024) void k_nms_reduce_band(const u64 *__restrict__ mask, const int32_t *__restrict__ order,
+                                                          const int32_t *__restrict__ counts, int64_t nmax, int64_t Np, int64_t W,
+                                                          int quirk, int64_t *__restrict__ keep, int32_t *__restrict__ keep_count,
+                                                          const int32_t *__restrict__ cflag)
 {
     if (cflag && cflag[blockIdx.x]) return;                   // k_nms_reduce_csr does this image
-    static_assert(T == 1024, "thread <-> (row, summary word) mapping assumes 1024 threads");
     extern __shared__ u64 nms_lds[];
-    __shared__ u64 sumring[2][64][16];
+    __shared__ u64 band[64 * BAND_BLOCKS * BAND_BLOCKS];      // [row in super-block][word in super-block]
+    __shared__ int klist[64 * BAND_BLOCKS];
+    __shared__ int s_nk, s_total, s_last_ib, s_last_r;
+    __shared__ u64 s_last_curb;
     u64 *remv2 = nms_lds, *remv1 = nms_lds + W;
-    constexpr int NW = T / 64, RPW = 64 / NW;
-    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int n = counts ? counts[img] : (int)nmax;
     mask += (int64_t)img * Np * W;
-    rsum += (int64_t)img * Np * SW;
     order += (int64_t)img * Np;
     keep += (int64_t)img * nmax;
-    for (int w = tid; w < (int)W; w += T) {
+    const int nb = (n + 63) >> 6, nsb = (nb + BAND_BLOCKS - 1) / BAND_BLOCKS;
+    for (int w = tid; w < (int)W; w += 1024) {
         const int64_t base = (int64_t)w * 64;
         const u64 v = (base >= n) ? ~0ull : ((n - base >= 64) ? 0ull : (~0ull << (n - base)));
         remv2[w] = v; remv1[w] = v;
     }
-    __syncthreads();
-    const int nb = (n + 63) >> 6, SWn = (nb + 63) >> 6;
-    int total = 0, last_ib = -1, last_r = 0;
-    u64 last_curb = 0;
-    const int quarter = lane & 3, sl = lane >> 2;
-    // summaries of the next block's 64 rows are fetched one block ahead into an LDS ring (they do not
-    // depend on what is kept); W <= 1024 here, so a row has at most 16 summary words
-    auto sum_fetch = [&](int b) -> u64 {
-        const int s = (b >> 6) + (tid & 15);
-        return (b < nb && s < SWn) ? rsum[((int64_t)b * 64 + (tid >> 4)) * SW + s] : 0ull;
+    auto band_fetch = [&](int S, u64 (&r)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int e = tid + 1024 * k, i = e >> 3, j = e & 7;
+            const int row = S * 64 * BAND_BLOCKS + i, w = S * BAND_BLOCKS + j;
+            r[k] = (S < nsb && row < nb * 64 && w < nb && w >= (row >> 6)) ? mask[(int64_t)row * W + w] : 0ull;
+        }
     };
-    sumring[0][tid >> 4][tid & 15] = sum_fetch(0);
+    u64 bnext[4];
+    band_fetch(0, bnext);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) band[tid + 1024 * k] = bnext[k];
+    if (tid == 0) { s_total = 0; s_last_ib = -1; s_last_r = 0; s_last_curb = 0; }
     __syncthreads();
-    u32 pbits = 0;          // the pending row's 16-word piece seen by this lane, and where it starts
-    int pwbase = 0;
-
-    u64 diag_next = (nb > 0) ? mask[(int64_t)lane * W] : 0ull;
-    int ahead = 0;                                          // block whose diagonal word and summaries were fetched ahead
-    for (int ib = 0; ib < nb; ++ib) {
-        u64 cur = uniform64(remv2[ib]);
-        if (cur == ~0ull) continue;                         // block already suppressed (uniform; nothing writes words <= ib now)
-        if (ahead != ib) {                                  // came here over skipped blocks: fetch now
-            diag_next = mask[((int64_t)ib * 64 + lane) * W + ib];
-            sumring[ib & 1][tid >> 4][tid & 15] = sum_fetch(ib);
-            __syncthreads();
-        }
-        const u64 diag = diag_next;
-        if (ib + 1 < nb) diag_next = mask[((int64_t)(ib + 1) * 64 + lane) * W + ib + 1];
-        const u64 sum_next = sum_fetch(ib + 1);
-        ahead = ib + 1;
-        u64 curb = cur;
-        int lastact = -1;
-        {
-            u64 m = uniform64(__ballot(diag != 0ull));
-            while (m) {
-                const int r = __builtin_ctzll(m);
-                m &= m - 1;
-                if (!((cur >> r) & 1ull)) { curb = cur; lastact = r; cur |= readlane64(diag, r); }
-            }
-        }
-        const u64 kept = ~cur;
-        const int nk = __builtin_popcountll(kept);
-        if (nk) {                                            // uniform
-            const int rl = 63 - __builtin_clzll(kept);
-            const bool mine = (kept >> lane) & 1ull;
-            const int rank = __builtin_popcountll(kept & ((1ull << lane) - 1ull));
-            if (wave == 0 && mine) keep[total + rank] = (int64_t)order[ib * 64 + lane];
-            // this wave's rows: the kept rows number wave, wave+NW, ...; the previous kept block's last row
-            // (for removed1 only) goes to wave nk % NW
-            int rr[RPW];
+    int pend = -1;                                            // last kept row so far (uniform in every thread)
+    for (int S = 0; S < nsb; ++S) {
+        band_fetch(S + 1, bnext);                             // in flight during both phases
+        if (tid < 64) {
+            int total = s_total, nk_sb = 0, last_ib = s_last_ib, last_r = s_last_r;
+            u64 last_curb = s_last_curb;
 #pragma unroll
-            for (int j = 0; j < RPW; ++j) {
-                const u64 b = __ballot(mine && rank == wave + NW * j);
-                rr[j] = b ? __builtin_ctzll(b) : -1;
-            }
-            const bool pend = last_ib >= 0 && (nk % NW) == wave;
-            const int64_t prow = (int64_t)last_ib * 64 + last_r;
-            const int s = (ib >> 6) + sl;
-            const int wbase = s * 64 + 16 * quarter;
-            auto live_from = [&](int base) -> u32 {          // words <= ib are of no further use
-                const int lo = ib - base;
-                return lo < 0 ? 0xffffu : (lo >= 15 ? 0u : ((0xffffu << (lo + 1)) & 0xffffu));
-            };
-            const u32 live = (s < SWn) ? live_from(wbase) : 0u;
-            u32 bits[RPW], bp = pend ? (pbits & live_from(pwbase)) : 0u;
+            for (int bb = 0; bb < BAND_BLOCKS; ++bb) {
+                const int ib = S * BAND_BLOCKS + bb;
+                if (ib < nb) {                                // uniform
+                    u64 cur = uniform64(remv2[ib]);
+                    if (cur != ~0ull) {
+                        u64 wd[BAND_BLOCKS];
 #pragma unroll
-            for (int j = 0; j < RPW; ++j)
-                bits[j] = (rr[j] >= 0) ? ((u32)(sumring[ib & 1][rr[j]][sl] >> (16 * quarter)) & live) : 0u;
-            for (;;) {
-                u32 any = bp;
+                        for (int j = bb; j < BAND_BLOCKS; ++j) wd[j] = band[(bb * 64 + lane) * BAND_BLOCKS + j];
+                        const u64 diag = wd[bb];
+                        u64 curb = cur;
+                        int lastact = -1;
+                        // hop over the rows that are still alive AND suppress something in their own block (a dense mask
+                        // leaves few alive, a sparse one has few non-zero diagonal words): the lowest such row is kept
+                        u64 act = ~cur & uniform64(__ballot(diag != 0ull));
+                        while (act) {
+                            const int r = __builtin_ctzll(act);
+                            curb = cur; lastact = r;
+                            cur |= readlane64(diag, r);
+                            act &= act - 1;
+                            act &= ~cur;
+                        }
+                        const u64 kept = ~cur;
+                        const int nk = __builtin_popcountll(kept);
+                        if (nk) {
+                            const bool mine = (kept >> lane) & 1ull;
+                            const int rank = __builtin_popcountll(kept & ((1ull << lane) - 1ull));
+                            if (mine) {
+                                keep[total + rank] = (int64_t)order[ib * 64 + lane];
+                                klist[nk_sb + rank] = ib * 64 + lane;
 #pragma unroll
-                for (int j = 0; j < RPW; ++j) any |= bits[j];
-                if (!any) break;
-                u64 v[RPW], vp = 0;
-                int wj[RPW], wp = 0;
-#pragma unroll
-                for (int j = 0; j < RPW; ++j) {
-                    v[j] = 0; wj[j] = 0;
-                    if (bits[j]) {
-                        wj[j] = wbase + __builtin_ctz(bits[j]);
-                        bits[j] &= bits[j] - 1;
-                        v[j] = mask[((int64_t)ib * 64 + rr[j]) * W + wj[j]];
+                                for (int j = bb + 1; j < BAND_BLOCKS; ++j)
+                                    if (wd[j]) atomicOr((unsigned long long *)&remv2[S * BAND_BLOCKS + j], (unsigned long long)wd[j]);
+                            }
+                            const int rl = 63 - __builtin_clzll(kept);
+                            last_ib = ib; last_r = rl; last_curb = (rl == lastact) ? curb : cur;
+                            total += nk; nk_sb += nk;
+                        }
                     }
                 }
-                if (bp) { wp = pwbase + __builtin_ctz(bp); bp &= bp - 1; vp = mask[prow * W + wp]; }
-#pragma unroll
-                for (int j = 0; j < RPW; ++j) {
-                    if (v[j]) {
-                        atomicOr((unsigned long long *)&remv2[wj[j]], (unsigned long long)v[j]);
-                        if (rr[j] != rl) atomicOr((unsigned long long *)&remv1[wj[j]], (unsigned long long)v[j]);
-                    }
-                }
-                if (vp) atomicOr((unsigned long long *)&remv1[wp], (unsigned long long)vp);
             }
-            pbits = (s < SWn) ? ((u32)(sumring[ib & 1][rl][sl] >> (16 * quarter)) & 0xffffu) : 0u;
-            pwbase = wbase;
-            last_ib = ib; last_r = rl; last_curb = (rl == lastact) ? curb : cur;
-            total += nk;
+            if (tid == 0) { s_nk = nk_sb; s_total = total; s_last_ib = last_ib; s_last_r = last_r; s_last_curb = last_curb; }
         }
-        sumring[(ib + 1) & 1][tid >> 4][tid & 15] = sum_next;
+        __syncthreads();
+        const int nk_sb = s_nk;
+        if (nk_sb) {
+            // word column w = tid of every row this super-block kept (all but the last one also into removed1), and of the
+            // row that was pending (removed1 only)
+            const int w = tid;
+            if (w < nb && w >= S * BAND_BLOCKS) {
+                u64 v2 = 0, v1 = 0;
+                int k = 0;
+                for (; k + 16 <= nk_sb - 1; k += 16) {        // 16 independent loads in flight: one round trip per 16 kept rows
+                    u64 v[16];
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) {
+                        const int row = klist[k + u];
+                        v[u] = (w > (row >> 6)) ? mask[(int64_t)row * W + w] : 0ull;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 16; ++u) v2 |= v[u];
+                }
+                for (; k + 4 <= nk_sb - 1; k += 4) {
+                    u64 v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int row = klist[k + u];
+                        v[u] = (w > (row >> 6)) ? mask[(int64_t)row * W + w] : 0ull;
+                    }
+                    v2 |= (v[0] | v[1]) | (v[2] | v[3]);
+                }
+                for (; k < nk_sb - 1; ++k) {
+                    const int row = klist[k];
+                    if (w > (row >> 6)) v2 |= mask[(int64_t)row * W + w];
+                }
+                v1 = v2;
+                {
+                    const int row = klist[nk_sb - 1];
+                    if (w > (row >> 6)) v2 |= mask[(int64_t)row * W + w];
+                }
+                if (pend >= 0 && w > (pend >> 6)) v1 |= mask[(int64_t)pend * W + w];
+                remv2[w] |= v2;
+                remv1[w] |= v1;
+            }
+            pend = klist[nk_sb - 1];
+        }
+        __syncthreads();                                       // phase 2 has read klist and the band is free
+#pragma unroll
+        for (int k = 0; k < 4; ++k) band[tid + 1024 * k] = bnext[k];
         __syncthreads();
     }
+    int total = s_total;
     if (quirk && total > 0) {
-        // yolo.py:196 `while ids_sorted.numel()>1`: the last kept box is dropped iff nothing ranked below it
-        // was still alive before its own row was applied.
+        const int last_ib = s_last_ib, last_r = s_last_r;
         const u64 above = (last_r == 63) ? 0ull : (~0ull << (last_r + 1));
-        int surv = (tid == 0) ? (((~last_curb) & above) != 0ull) : 0;
-        for (int w = last_ib + 1 + tid; w < (int)W; w += T) surv |= (~remv1[w]) != 0ull;
+        int surv = (tid == 0) ? (((~s_last_curb) & above) != 0ull) : 0;
+        for (int w = last_ib + 1 + tid; w < (int)W; w += 1024) surv |= (~remv1[w]) != 0ull;
         surv = __syncthreads_or(surv);
         if (!surv) total -= 1;
     }
@@ -535,7 +552,7 @@ __global__ __launch_bounds__(T) void k_nms_reduce_sum(const u64 *__restrict__ ma
 }
 
 // ---------------------------------------------------------------- compact mask + LDS-fed reduce (64 < W <= 1024)
-// k_nms_reduce_sum pays one HBM round trip per 64-row block (about 2 us): the words it needs are only known once the
+// A reduce that walks the mask itself pays one HBM round trip per 64-row block (about 2 us): the words it needs are only known once the
 // block is resolved.  Here the non-zero words right of the diagonal are first gathered, per block, into one contiguous
 // run of (row-in-block << 16 | word, bits) entries -- a few MB in all -- which does not depend on what is kept.  The
 // reduce fetches each block's run, diagonal words and order 8 blocks ahead into registers (one entry per thread) and
@@ -597,7 +614,7 @@ __global__ __launch_bounds__(1024) void k_nms_csr_scan(const int32_t *__restrict
     }
     if (tid == 0) {
         boff[(int64_t)img * (W + 1) + nb] = fits ? (int32_t)total : 0;
-        cflag[img] = fits ? 1 : 0;
+        cflag[img] = fits ? 1 : 0;                                   // 0: too dense for the compact form, k_nms_reduce_band
     }
 }
 
@@ -608,7 +625,7 @@ __global__ __launch_bounds__(256) void k_nms_csr_fill(const u64 *__restrict__ ma
                                                       int32_t *__restrict__ cursor, u32 *__restrict__ ekey, u64 *__restrict__ eval)
 {
     const int img = blockIdx.y;
-    if (!cflag[img]) return;
+    if (cflag[img] != 1) return;
     const int n = counts ? counts[img] : (int)nmax;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t i = t / SW;
@@ -690,7 +707,7 @@ __global__ __launch_bounds__(1024) void k_nms_reduce_csr(const u64 *__restrict__
     __shared__ int s_len[2], s_new[2];
     __shared__ int32_t s_boff[1025];                          // block offsets: read every iteration, keep them out of the memory path
     const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (!cflag[img]) return;                                  // too dense: k_nms_reduce_sum does this image
+    if (cflag[img] != 1) return;                              // too dense: k_nms_reduce_band does this image
     const int n = counts ? counts[img] : (int)nmax;
     mask += (int64_t)img * Np * W;
     order += (int64_t)img * Np;
@@ -928,8 +945,10 @@ extern "C" int dg_nms_phase_reduce(const int32_t *counts, int64_t batch, int64_t
         // compact the mask, then the LDS-fed reduce; an image whose entries do not fit falls to the summary-driven kernel
         hipLaunchKernelGGL(k_nms_csr_count, dim3((unsigned)(w.Np / 256 + (w.Np % 256 != 0)), (unsigned)batch), dim3(256), 0, st, w.rsum,
                            counts, nmax, w.Np, w.W, w.SW, w.bcnt);
-        hipLaunchKernelGGL(k_nms_csr_scan, dim3((unsigned)batch), dim3(1024), 0, st, w.bcnt, counts, nmax, w.W, w.ecap, w.boff, w.cursor,
-                           w.cflag);
+        // DG_NMS_FORCE_FALLBACK=1 (tests): no image "fits" the compact form, every one takes the dense-mask reduce
+        const bool force_fb = getenv("DG_NMS_FORCE_FALLBACK") && atoi(getenv("DG_NMS_FORCE_FALLBACK")) != 0;
+        hipLaunchKernelGGL(k_nms_csr_scan, dim3((unsigned)batch), dim3(1024), 0, st, w.bcnt, counts, nmax, w.W, force_fb ? (int64_t)-1 : w.ecap,
+                           w.boff, w.cursor, w.cflag);
         if ((w.SW & (w.SW - 1)) == 0 && w.SW <= 64) {
             int sh = 0;
             while ((1ll << sh) < w.SW) ++sh;
@@ -941,8 +960,9 @@ extern "C" int dg_nms_phase_reduce(const int32_t *counts, int64_t batch, int64_t
         }
         hipLaunchKernelGGL(k_nms_reduce_csr, dim3((unsigned)batch), dim3(1024), 0, st, w.mask, w.order, counts, nmax, w.Np, w.W, w.ecap,
                            w.cflag, w.boff, w.ekey, w.eval, quirk_drop_last, keep, keep_count);
-        hipLaunchKernelGGL((k_nms_reduce_sum<1024>), dim3((unsigned)batch), dim3(1024), (size_t)w.W * 16, st, w.mask, w.rsum, w.order,
-                           counts, nmax, w.Np, w.W, w.SW, quirk_drop_last, keep, keep_count, w.cflag);
+        // images whose compact form overflowed (dense masks); returns at once for the others
+        hipLaunchKernelGGL(k_nms_reduce_band, dim3((unsigned)batch), dim3(1024), (size_t)w.W * 16, st, w.mask, w.order, counts, nmax,
+                           w.Np, w.W, quirk_drop_last, keep, keep_count, w.cflag);
     }
     else if (w.W <= 4096) RED(1024, 4);
     else RED(1024, 16);
