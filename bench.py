@@ -410,6 +410,7 @@ def extra_kmeans(d, n_total=10_000_000, iters=30):
                  "timed: best of 5 runs of 30 iterations, device-resident; the inertia sum is formed by the last iteration of a "
                  "run only, on one rank and on many alike; device_ms_per_iter = HIP-event time of the same 30 iterations / 30 "
                  "(k_kmeans_step is VALU-bound: iter_valu_frac = SQ_INSTS_VALU x 64 / time over the chip's 7.86e13 lane-ops/s)"}
+    km.close()                                   # frees the library-side communicator, if this fit made one (collective)
     if d.world == 1 and not d.rehearse:
         # what the sharded loop costs per iteration on a 1/8 shard (1.25 M boxes), all-reduce included, on this one GPU:
         # a single-rank RCCL group runs the same launch + all-reduce sequence the 8-GPU job runs on every rank
