@@ -562,8 +562,16 @@ def main():
     # the same step with the argmax kept as uint16 (what slowroipool's autograd path does; H*W <= 65535): every rank runs it
     a16 = None
     if not a.no_extras:
+        err = None
         try:
             w.arg = torch.empty(tuple(w.out.shape), dtype=torch.int16, device=d.dev)
+        except torch.OutOfMemoryError as e:
+            err = str(e)
+        # every rank takes part in the timed region's barriers or none does: a rank that skipped them alone would pair its
+        # next collective with the others' barriers
+        if d.max(0.0 if err is None else 1.0) > 0.0:
+            a16 = {"error": err or "another rank ran out of memory"}
+        else:
             sec16 = d.timed(w.step, a.steps, 1)
             f16, b16 = ev_median(w.fwd, 20, 5), ev_median(w.bwd, 20, 5)
             a16 = {"value": total_rois * a.steps / sec16, "unit": "RoIs/s", "ms_per_step": sec16 / a.steps * 1e3,
@@ -572,8 +580,6 @@ def main():
                    "bwd_hbm_frac": (w.n * ROI_BYTES_A16 + w.B * MAP_BYTES) / (b16 * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                    "note": "same step, argmax stored as uint16 instead of int32: the primary line keeps the int32 layout "
                            "BASELINE configs[2] sizes (51.4 GB of argmax); fractions here use this layout's own bytes"}
-        except torch.OutOfMemoryError as e:
-            a16 = {"error": str(e)}
     del w
     torch.cuda.empty_cache()
     extra = {"phases_ms_rank0": phases, "grad_out_aliases_out": gout_alias, "config3_uint16_argmax": a16}
@@ -582,6 +588,7 @@ def main():
 
     def side(name, fn):
         # a side configuration that fails is reported as such; it must not cost the primary line
+        trace(d, f"{name} ...")
         try:
             extra[name] = fn(d)
         except Exception as e:  # noqa: BLE001
@@ -591,7 +598,13 @@ def main():
     # ONE 256-image batch split over the ranks (BASELINE configs[2] as worded), next to the weak-scaling primary line
     if d.world > 1 and a.scaling == "weak" and not a.no_extras:
         def strong(d):
-            ws = FrcnnBatch(d, a.images)
+            ws, err = None, None
+            try:
+                ws = FrcnnBatch(d, a.images)
+            except torch.OutOfMemoryError as e:
+                err = str(e)
+            if d.max(0.0 if err is None else 1.0) > 0.0:       # all ranks or none enter the timed region's barriers
+                return {"error": err or "another rank ran out of memory"}
             sec_s = d.timed(ws.step, a.steps, a.warmup)
             ws.check()
             return {"value": a.images * ws.n_rois * a.steps / sec_s, "unit": "RoIs/s", "ms_per_step": sec_s / a.steps * 1e3,
