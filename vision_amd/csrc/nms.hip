@@ -393,18 +393,23 @@ __global__ __launch_bounds__(T) void k_nms_reduce(const u64 *__restrict__ mask, 
 // ---------------------------------------------------------------- reduce for DENSE masks (8 <= W <= 1024, compact form overflowed)
 // Round 1's kernel here (k_nms_reduce_sum: row summaries, only the non-zero words of kept rows) paid one HBM round trip
 // per 64-row block: the words of the rows it keeps can be fetched only once the block is resolved (2.43 ms for 64k dense
-// boxes at thr 0.5; this kernel 1.17 ms).  But the next blocks need only the NEAR words of those rows.  So the chain runs over SUPER-BLOCKS of
-// 8 blocks (512 rows):
-//   band:    the 512 x 8 words [rows of the super-block] x [its own 8 word columns] depend on nothing: they are fetched a
-//            super-block ahead (4 words per thread in registers) and live in LDS (32 KB);
-//   phase 1: wave 0 alone resolves the 8 blocks from the band -- diagonal word by v_readlane chain as in the other
-//            reduces, the kept rows' near words (inside the super-block) OR-ed into `removed` with LDS atomics, which one
-//            wave sees in order: no barrier inside a super-block;
-//   phase 2: every thread owns one word column w: it ORs word w of ALL rows the super-block kept into removed[w] -- the
-//            loads of a super-block are independent, one HBM round trip per 512 rows instead of one per 64.
-// removed1 lags by the last kept row of the latest super-block that kept anything (`pend`): it ends as "everything but the
-// last kept box", which is what the numel()>1 quirk asks about (yolo.py:196).
+// boxes at thr 0.5; this kernel 0.92 ms).  But the next blocks need only the NEAR words of those rows.  So the chain runs
+// over SUPER-BLOCKS of 8 blocks (512 rows), in two concurrent roles:
+//   band:     the 512 x 16 words [rows of super-block S] x [word columns of S and S+1] depend on nothing: they are fetched a
+//             super-block ahead (8 words per thread in registers) and live in LDS (64 KB), with the rows' `order`;
+//   resolver: wave 0 alone resolves the 8 blocks of S from the band -- diagonal word by v_readlane chain, hopping over the
+//             rows that are alive and suppress something in their own block; the kept rows' near words are OR-ed into
+//             `removed` with LDS atomics, which one wave sees in order: no barrier inside a super-block;
+//   far side: meanwhile the other 15 waves fetch the FAR words (>= (S+1)*8, first needed by S+1) of everything S-1 kept:
+//             thread = word column, 16 independent loads in flight, one HBM round trip per 512 rows instead of one per 64.
+// One barrier pair per super-block; whichever side is slower sets its time (here the resolver: ~0.55 us per block, about
+// 300 instructions of a lone wave).  `removed1` (everything but the last kept box, for the quirk of yolo.py:196) is kept
+// by the far side alone: the last kept row of a super-block stays pending until a later super-block keeps something.
+// A serial version of the same idea (resolve, barrier, far, barrier; band one super-block wide) took 1.17 ms.
 #define BAND_BLOCKS 8
+#define PIPE_NEAR (2 * BAND_BLOCKS)
+#define PIPE_ROWS (64 * BAND_BLOCKS + 1)   // band[word][row], one row of padding: the resolver reads 64 consecutive rows of a
+                                          // word (conflict-free), the fill writes 16 words of 4 rows per wave (banks 2j + 2i)
 __global__ __launch_bounds__(1024) void k_nms_reduce_band(const u64 *__restrict__ mask, const int32_t *__restrict__ order,
                                                           const int32_t *__restrict__ counts, int64_t nmax, int64_t Np, int64_t W,
                                                           int quirk, int64_t *__restrict__ keep, int32_t *__restrict__ keep_count,
@@ -412,139 +417,140 @@ __global__ __launch_bounds__(1024) void k_nms_reduce_band(const u64 *__restrict_
 {
     if (cflag && cflag[blockIdx.x]) return;                   // k_nms_reduce_csr does this image
     extern __shared__ u64 nms_lds[];
-    __shared__ u64 band[64 * BAND_BLOCKS * BAND_BLOCKS];      // [row in super-block][word in super-block]
-    __shared__ int klist[64 * BAND_BLOCKS];
-    __shared__ int s_nk, s_total, s_last_ib, s_last_r;
+    u64 *removed = nms_lds, *removed1 = nms_lds + W, *band = nms_lds + 2 * W;      // band: [PIPE_NEAR][PIPE_ROWS]
+    __shared__ int klist[2][64 * BAND_BLOCKS];
+    __shared__ int s_order[64 * BAND_BLOCKS];                 // `order` of the super-block's rows: a global load in the resolver's
+                                                              // path would stall its in-order wave for a memory round trip per block
+    __shared__ int s_nk[2], s_total, s_last_ib, s_last_r;
     __shared__ u64 s_last_curb;
-    u64 *remv2 = nms_lds, *remv1 = nms_lds + W;
     const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int n = counts ? counts[img] : (int)nmax;
     mask += (int64_t)img * Np * W;
     order += (int64_t)img * Np;
     keep += (int64_t)img * nmax;
     const int nb = (n + 63) >> 6, nsb = (nb + BAND_BLOCKS - 1) / BAND_BLOCKS;
-    for (int w = tid; w < (int)W; w += 1024) {
+    auto init_word = [&](int w) -> u64 {
         const int64_t base = (int64_t)w * 64;
-        const u64 v = (base >= n) ? ~0ull : ((n - base >= 64) ? 0ull : (~0ull << (n - base)));
-        remv2[w] = v; remv1[w] = v;
-    }
-    auto band_fetch = [&](int S, u64 (&r)[4]) {
+        return (base >= n) ? ~0ull : ((n - base >= 64) ? 0ull : (~0ull << (n - base)));
+    };
+    for (int w = tid; w < (int)W; w += 1024) { removed[w] = init_word(w); removed1[w] = init_word(w); }
+    auto band_fetch = [&](int S, u64 (&r)[8]) {
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int e = tid + 1024 * k, i = e >> 3, j = e & 7;
+        for (int k = 0; k < 8; ++k) {
+            const int e = tid + 1024 * k, i = e >> 4, j = e & 15;
             const int row = S * 64 * BAND_BLOCKS + i, w = S * BAND_BLOCKS + j;
             r[k] = (S < nsb && row < nb * 64 && w < nb && w >= (row >> 6)) ? mask[(int64_t)row * W + w] : 0ull;
         }
     };
-    u64 bnext[4];
-    band_fetch(0, bnext);
+    auto order_fetch = [&](int S) -> int {
+        const int row = S * 64 * BAND_BLOCKS + tid;
+        return (tid < 64 * BAND_BLOCKS && row < nb * 64) ? order[row] : 0;
+    };
+    u64 bn[8];
+    int on = order_fetch(0);
+    if (tid < 64 * BAND_BLOCKS) s_order[tid] = on;
+    band_fetch(0, bn);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) band[tid + 1024 * k] = bnext[k];
-    if (tid == 0) { s_total = 0; s_last_ib = -1; s_last_r = 0; s_last_curb = 0; }
+    for (int k = 0; k < 8; ++k) { const int e = tid + 1024 * k; band[(e & 15) * PIPE_ROWS + (e >> 4)] = bn[k]; }
+    if (tid == 0) { s_total = 0; s_last_ib = -1; s_last_r = 0; s_last_curb = 0; s_nk[0] = 0; s_nk[1] = 0; }
     __syncthreads();
-    int pend = -1;                                            // last kept row so far (uniform in every thread)
-    for (int S = 0; S < nsb; ++S) {
-        band_fetch(S + 1, bnext);                             // in flight during both phases
+    int pend = -1;                                            // last kept row of the super-blocks the far side has seen
+    for (int S = 0; S <= nsb; ++S) {
+        band_fetch(S + 1, bn);                                // in flight while both sides work
+        on = order_fetch(S + 1);
         if (tid < 64) {
-            int total = s_total, nk_sb = 0, last_ib = s_last_ib, last_r = s_last_r;
-            u64 last_curb = s_last_curb;
+            if (S < nsb) {
+                int total = s_total, nk_sb = 0, last_ib = s_last_ib, last_r = s_last_r;
+                u64 last_curb = s_last_curb;
 #pragma unroll
-            for (int bb = 0; bb < BAND_BLOCKS; ++bb) {
-                const int ib = S * BAND_BLOCKS + bb;
-                if (ib < nb) {                                // uniform
-                    u64 cur = uniform64(remv2[ib]);
-                    if (cur != ~0ull) {
-                        u64 wd[BAND_BLOCKS];
+                for (int bb = 0; bb < BAND_BLOCKS; ++bb) {
+                    const int ib = S * BAND_BLOCKS + bb;
+                    if (ib < nb) {                            // uniform
+                        u64 cur = uniform64(removed[ib]);
+                        if (cur != ~0ull) {
+                            u64 wd[PIPE_NEAR];
 #pragma unroll
-                        for (int j = bb; j < BAND_BLOCKS; ++j) wd[j] = band[(bb * 64 + lane) * BAND_BLOCKS + j];
-                        const u64 diag = wd[bb];
-                        u64 curb = cur;
-                        int lastact = -1;
-                        // hop over the rows that are still alive AND suppress something in their own block (a dense mask
-                        // leaves few alive, a sparse one has few non-zero diagonal words): the lowest such row is kept
-                        u64 act = ~cur & uniform64(__ballot(diag != 0ull));
-                        while (act) {
-                            const int r = __builtin_ctzll(act);
-                            curb = cur; lastact = r;
-                            cur |= readlane64(diag, r);
-                            act &= act - 1;
-                            act &= ~cur;
-                        }
-                        const u64 kept = ~cur;
-                        const int nk = __builtin_popcountll(kept);
-                        if (nk) {
-                            const bool mine = (kept >> lane) & 1ull;
-                            const int rank = __builtin_popcountll(kept & ((1ull << lane) - 1ull));
-                            if (mine) {
-                                keep[total + rank] = (int64_t)order[ib * 64 + lane];
-                                klist[nk_sb + rank] = ib * 64 + lane;
-#pragma unroll
-                                for (int j = bb + 1; j < BAND_BLOCKS; ++j)
-                                    if (wd[j]) atomicOr((unsigned long long *)&remv2[S * BAND_BLOCKS + j], (unsigned long long)wd[j]);
+                            for (int j = bb; j < PIPE_NEAR; ++j) wd[j] = band[j * PIPE_ROWS + bb * 64 + lane];
+                            const u64 diag = wd[bb];
+                            u64 curb = cur;
+                            int lastact = -1;
+                            u64 act = ~cur & uniform64(__ballot(diag != 0ull));
+                            while (act) {
+                                const int r = __builtin_ctzll(act);
+                                curb = cur; lastact = r;
+                                cur |= readlane64(diag, r);
+                                act &= act - 1;
+                                act &= ~cur;
                             }
-                            const int rl = 63 - __builtin_clzll(kept);
-                            last_ib = ib; last_r = rl; last_curb = (rl == lastact) ? curb : cur;
-                            total += nk; nk_sb += nk;
+                            const u64 kept = ~cur;
+                            const int nk = __builtin_popcountll(kept);
+                            if (nk) {
+                                const bool mine = (kept >> lane) & 1ull;
+                                const int rank = __builtin_popcountll(kept & ((1ull << lane) - 1ull));
+                                if (mine) {
+                                    keep[total + rank] = (int64_t)s_order[bb * 64 + lane];
+                                    klist[S & 1][nk_sb + rank] = ib * 64 + lane;
+#pragma unroll
+                                    for (int j = bb + 1; j < PIPE_NEAR; ++j)
+                                        if (wd[j]) atomicOr((unsigned long long *)&removed[S * BAND_BLOCKS + j], (unsigned long long)wd[j]);
+                                }
+                                const int rl = 63 - __builtin_clzll(kept);
+                                last_ib = ib; last_r = rl; last_curb = (rl == lastact) ? curb : cur;
+                                total += nk; nk_sb += nk;
+                            }
                         }
                     }
                 }
+                if (tid == 0) { s_nk[S & 1] = nk_sb; s_total = total; s_last_ib = last_ib; s_last_r = last_r; s_last_curb = last_curb; }
             }
-            if (tid == 0) { s_nk = nk_sb; s_total = total; s_last_ib = last_ib; s_last_r = last_r; s_last_curb = last_curb; }
-        }
-        __syncthreads();
-        const int nk_sb = s_nk;
-        if (nk_sb) {
-            // word column w = tid of every row this super-block kept (all but the last one also into removed1), and of the
-            // row that was pending (removed1 only)
-            const int w = tid;
-            if (w < nb && w >= S * BAND_BLOCKS) {
-                u64 v2 = 0, v1 = 0;
-                int k = 0;
-                for (; k + 16 <= nk_sb - 1; k += 16) {        // 16 independent loads in flight: one round trip per 16 kept rows
-                    u64 v[16];
+        } else if (S >= 1) {
+            // what super-block S-1 kept: its far words (its band reached word (S+1)*8 - 1) go into `removed`; every word
+            // right of a row's own block also goes into `removed1`, except for the super-block's last kept row, which
+            // stays pending until a later super-block keeps something
+            const int nk_prev = s_nk[(S - 1) & 1];
+            const int *kl = klist[(S - 1) & 1];
+            if (nk_prev) {
+                const int far0 = (S + 1) * BAND_BLOCKS;
+                for (int w = (S - 1) * BAND_BLOCKS + (tid - 64); w < nb; w += 1024 - 64) {
+                    u64 v1 = 0;
+                    int k = 0;
+                    for (; k + 16 <= nk_prev - 1; k += 16) {   // 16 independent loads in flight
+                        u64 v[16];
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) {
-                        const int row = klist[k + u];
-                        v[u] = (w > (row >> 6)) ? mask[(int64_t)row * W + w] : 0ull;
+                        for (int u = 0; u < 16; ++u) { const int row = kl[k + u]; v[u] = (w > (row >> 6)) ? mask[(int64_t)row * W + w] : 0ull; }
+#pragma unroll
+                        for (int u = 0; u < 16; ++u) v1 |= v[u];
                     }
+                    for (; k + 4 <= nk_prev - 1; k += 4) {
+                        u64 v[4];
 #pragma unroll
-                    for (int u = 0; u < 16; ++u) v2 |= v[u];
-                }
-                for (; k + 4 <= nk_sb - 1; k += 4) {
-                    u64 v[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int row = klist[k + u];
-                        v[u] = (w > (row >> 6)) ? mask[(int64_t)row * W + w] : 0ull;
+                        for (int u = 0; u < 4; ++u) { const int row = kl[k + u]; v[u] = (w > (row >> 6)) ? mask[(int64_t)row * W + w] : 0ull; }
+                        v1 |= (v[0] | v[1]) | (v[2] | v[3]);
                     }
-                    v2 |= (v[0] | v[1]) | (v[2] | v[3]);
+                    for (; k < nk_prev - 1; ++k) { const int row = kl[k]; if (w > (row >> 6)) v1 |= mask[(int64_t)row * W + w]; }
+                    const int lrow = kl[nk_prev - 1];
+                    const u64 vl = (w > (lrow >> 6)) ? mask[(int64_t)lrow * W + w] : 0ull;
+                    const u64 vp = (pend >= 0) ? mask[(int64_t)pend * W + w] : 0ull;       // w >= (S-1)*8 > pend's block
+                    if (w >= far0 && (v1 | vl)) atomicOr((unsigned long long *)&removed[w], (unsigned long long)(v1 | vl));
+                    removed1[w] |= v1 | vp;
                 }
-                for (; k < nk_sb - 1; ++k) {
-                    const int row = klist[k];
-                    if (w > (row >> 6)) v2 |= mask[(int64_t)row * W + w];
-                }
-                v1 = v2;
-                {
-                    const int row = klist[nk_sb - 1];
-                    if (w > (row >> 6)) v2 |= mask[(int64_t)row * W + w];
-                }
-                if (pend >= 0 && w > (pend >> 6)) v1 |= mask[(int64_t)pend * W + w];
-                remv2[w] |= v2;
-                remv1[w] |= v1;
             }
-            pend = klist[nk_sb - 1];
         }
-        __syncthreads();                                       // phase 2 has read klist and the band is free
+        if (S >= 1 && s_nk[(S - 1) & 1]) pend = klist[(S - 1) & 1][s_nk[(S - 1) & 1] - 1];
+        __syncthreads();                                       // resolve(S) and far(S-1) done: the band is free
 #pragma unroll
-        for (int k = 0; k < 4; ++k) band[tid + 1024 * k] = bnext[k];
+        for (int k = 0; k < 8; ++k) { const int e = tid + 1024 * k; band[(e & 15) * PIPE_ROWS + (e >> 4)] = bn[k]; }
+        if (tid < 64 * BAND_BLOCKS) s_order[tid] = on;
         __syncthreads();
     }
     int total = s_total;
     if (quirk && total > 0) {
+        // yolo.py:196 `while ids_sorted.numel()>1`: the last kept box is dropped iff nothing ranked below it was still alive
+        // before its own row was applied (removed1 = every kept row but that one)
         const int last_ib = s_last_ib, last_r = s_last_r;
         const u64 above = (last_r == 63) ? 0ull : (~0ull << (last_r + 1));
         int surv = (tid == 0) ? (((~s_last_curb) & above) != 0ull) : 0;
-        for (int w = last_ib + 1 + tid; w < (int)W; w += 1024) surv |= (~remv1[w]) != 0ull;
+        for (int w = last_ib + 1 + tid; w < (int)W; w += 1024) surv |= (~removed1[w]) != 0ull;
         surv = __syncthreads_or(surv);
         if (!surv) total -= 1;
     }
@@ -961,8 +967,14 @@ extern "C" int dg_nms_phase_reduce(const int32_t *counts, int64_t batch, int64_t
         hipLaunchKernelGGL(k_nms_reduce_csr, dim3((unsigned)batch), dim3(1024), 0, st, w.mask, w.order, counts, nmax, w.Np, w.W, w.ecap,
                            w.cflag, w.boff, w.ekey, w.eval, quirk_drop_last, keep, keep_count);
         // images whose compact form overflowed (dense masks); returns at once for the others
-        hipLaunchKernelGGL(k_nms_reduce_band, dim3((unsigned)batch), dim3(1024), (size_t)w.W * 16, st, w.mask, w.order, counts, nmax,
-                           w.Np, w.W, quirk_drop_last, keep, keep_count, w.cflag);
+        {
+            const size_t lds = (size_t)w.W * 16 + (size_t)PIPE_ROWS * PIPE_NEAR * 8;      // removed, removed1, 64 KB band
+            // per device, not a stream operation (no allocation, legal during capture); set on every call: a process may drive several devices
+            const hipError_t attr = hipFuncSetAttribute((const void *)k_nms_reduce_band, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+            if (attr != hipSuccess) { dg_set_error("nms_reduce: cannot raise the LDS limit of k_nms_reduce_band: %s", hipGetErrorString(attr)); return DG_EHIP; }
+            hipLaunchKernelGGL(k_nms_reduce_band, dim3((unsigned)batch), dim3(1024), lds, st, w.mask, w.order, counts, nmax,
+                               w.Np, w.W, quirk_drop_last, keep, keep_count, w.cflag);
+        }
     }
     else if (w.W <= 4096) RED(1024, 4);
     else RED(1024, 16);
