@@ -60,13 +60,16 @@ __device__ __forceinline__ int km_assign(float w, float h, const float (&cw)[KMA
 }
 
 // Assignment pre-filter.  The five IEEE divisions of km_assign are two thirds of the kernel, yet the winner is
-// rarely in doubt: a = inter * rcp(uni) is within 1.5 * 2^-23 (relative) of the exact quotient q.  The cluster index
+// rarely in doubt.  The key of cluster c is a = inter * rcp(area + A_c), within 2.5 * 2^-23 (relative) of x = inter /
+// (area + A_c); the IoU is q = inter / (area + A_c - inter) = x / (1 - x), increasing in x, and for x_a > x_b
+// q_a / q_b = (x_a / x_b) * (1 - x_b) / (1 - x_a) >= x_a / x_b: a relative gap between two keys is at least as wide between
+// the quotients (round 2: the subtraction of `inter` left the key, one operation per cluster).  The cluster index
 // replaces the low four mantissa bits (another 15 ulp), and an unsigned max / median-of-three pair keeps the two
-// largest keys m1 >= m2.  When m1 - m2 > 256 ulp (>= 2^-16 relative) and m1 >= 2^-5, the exact quotients differ by
-// more than q * 2^-17 >= 2^-22, i.e. by several ulps of d = fl(1 - q): that cluster wins the exact comparison
-// strictly, whatever the index order, and only its d is evaluated exactly.  Anything else (near ties, tiny overlaps,
-// NaN/inf/negative keys, which the unsigned max drags into m1) takes km_assign.  Callers bound |w|+|h| < 2^19 and
-// centroid areas < 2^60 so that rcp(uni) stays a normal number.
+// largest keys m1 >= m2.  When m1 - m2 > 256 ulp (>= 2^-16 relative) and m1 >= 2^-5 (so q >= x >= 2^-5), the exact
+// quotients differ by more than q * 2^-17 >= 2^-22, i.e. by several ulps of d = fl(1 - q): that cluster wins the exact
+// comparison strictly, whatever the index order, and only its d is evaluated exactly.  Anything else (near ties, tiny
+// overlaps, NaN/inf/negative keys, which the unsigned max drags into m1) takes km_assign.  Callers bound |w|+|h| < 2^19
+// and centroid areas < 2^60 so that rcp(area + A_c) stays a normal number.
 #define KM_GAP_MIN 256u
 #define KM_KEY_LO 0x3D000000u           /* 2^-5 */
 #define KM_KEY_HI 0x7F800000u           /* +inf: NaN and sign-bit keys compare above it */
@@ -86,8 +89,8 @@ __device__ __forceinline__ bool km_filter(float w, float h, const float (&cw)[KM
     for (int c = 0; c < KMAX; ++c) {
         if (FULL || c < k) {
             const float inter = fminf(w, cw[c]) * fminf(h, ch[c]);
-            const float uni = (area + (cw[c] * ch[c])) - inter;
-            const unsigned key = (__float_as_uint(inter * __builtin_amdgcn_rcpf(uni)) & ~15u) | (unsigned)c;
+            const float sum = area + (cw[c] * ch[c]);
+            const unsigned key = (__float_as_uint(inter * __builtin_amdgcn_rcpf(sum)) & ~15u) | (unsigned)c;
             m2 = umed3(m1, m2, key);
             m1 = max(m1, key);
         }
