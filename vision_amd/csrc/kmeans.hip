@@ -79,21 +79,38 @@ __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c)
     asm("v_med3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+__device__ __forceinline__ unsigned umax3(unsigned a, unsigned b, unsigned c)
+{
+    unsigned r;
+    asm("v_max3_u32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 template <int KMAX, bool FULL>
 __device__ __forceinline__ bool km_filter(float w, float h, const float (&cw)[KMAX], const float (&ch)[KMAX], int k, unsigned gap_min,
                                           int &best)
 {
     const float area = w * h;
-    unsigned m1 = 0, m2 = 0;
+    unsigned key[KMAX];
 #pragma unroll
     for (int c = 0; c < KMAX; ++c) {
+        key[c] = 0u;
         if (FULL || c < k) {
             const float inter = fminf(w, cw[c]) * fminf(h, ch[c]);
             const float sum = area + (cw[c] * ch[c]);
-            const unsigned key = (__float_as_uint(inter * __builtin_amdgcn_rcpf(sum)) & ~15u) | (unsigned)c;
-            m2 = umed3(m1, m2, key);
-            m1 = max(m1, key);
+            key[c] = (__float_as_uint(inter * __builtin_amdgcn_rcpf(sum)) & ~15u) | (unsigned)c;
         }
+    }
+    // the two largest keys: max3 / med3 of the first three, then one med3 + one max per further key
+    unsigned m1, m2;
+    if (KMAX >= 3) {
+        m1 = umax3(key[0], key[1], key[2]);
+        m2 = umed3(key[0], key[1], key[2]);
+#pragma unroll
+        for (int c = 3; c < KMAX; ++c) { m2 = umed3(m1, m2, key[c]); m1 = max(m1, key[c]); }
+    } else {
+        m1 = 0; m2 = 0;
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c) { m2 = umed3(m1, m2, key[c]); m1 = max(m1, key[c]); }
     }
     best = (int)(m1 & 15u);
     return (m1 - m2 > gap_min) && (m1 - KM_KEY_LO < KM_KEY_HI - KM_KEY_LO);
