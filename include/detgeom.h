@@ -226,7 +226,9 @@ int dg_kmeans_labels_i32(const uint8_t *labels, int64_t n, int32_t *out, dg_stre
  *                     (vision_amd.cluster broadcasts it through torch.distributed);
  *  dg_comm_init:      collective over the `nranks` callers, each with ITS device current; *out = the handle (host object,
  *                     freed by dg_comm_destroy);
- *  dg_comm_allreduce_i64: in-place SUM of buf[count] (device) over the ranks, asynchronous on stream s. */
+ *  dg_comm_allreduce_i64: in-place SUM of buf[count] (device) over the ranks, asynchronous on stream s.
+ * A communicator is driven by one host thread at a time (like an ncclComm_t), and every rank issues the same sequence of
+ * calls on it. */
 #define DG_COMM_ID_BYTES 128
 typedef struct dg_comm dg_comm_t;
 int dg_comm_unique_id(void *id_host);
