@@ -257,6 +257,16 @@ int dg_comm_graph_state(const dg_comm_t *c);
 int dg_rcnn_calcul_f32(const float *positive, int64_t n, const float *grt, float *t, dg_stream_t s);
 int dg_rcnn_decode_f32(const int32_t *p_rect, const float *tset, int64_t n, int variant, float *g, dg_stream_t s);
 
+/* The quota walk of do_ss ("next" row 4): rcnn/rcnn.py:35-65 (pos_thr 0.1, neg_thr 0.1, quota_neg = 2*min_num) and
+ * rcnn/fast_rcnn.py:123-155 (0.5, 0.1, quota_neg = min_num).  iou / flags: what dg_iou_rois_vs_gt_f64 wrote for the image's
+ * proposals, in proposal order.  sel / lab (2n int32 each): the proposals taken, in the order the reference appends them
+ * (a positive before a negative of the same proposal), with `label` for positives and 0 for negatives.
+ * out[0] = how many; out[1] = status: bit 0 = a visited proposal carries an assert flag (the reference raises
+ * AssertionError there), bit 1 / bit 2 = the positive / negative quota was found full (the reference's fflag / bflag). */
+int dg_rcnn_label_quota_f64(const double *iou, const int32_t *flags, int64_t n, int64_t min_num, int64_t quota_neg,
+                            double pos_thr, double neg_thr, int32_t label, int32_t *sel, int32_t *lab, int32_t *out,
+                            dg_stream_t s);
+
 /* ---------------------------------------------------------------- YOLOv1 loss, box geometry fused ("next" row 1)
  * Loss.forward(modely, targety): yolo/yolo_v1/modules.py:234-306 -- in-loss decode :262-268, IoU :271-272,
  * responsible-slot select :275-276, terms :283-302, combination :304-305.  modely/targety: (n,7,7,10+num_classes)

@@ -815,6 +815,35 @@ def test_rcnn_boxreg_golden(va, golden):
         np.testing.assert_allclose(got.numpy(), g[key], rtol=1e-6, atol=1e-4)
 
 
+def test_label_proposals_quota_walk_vs_oracle(va, oracle):
+    """dg_rcnn_label_quota_f64 (the ordered quota walk of do_ss as a device scan) against the oracle's literal loop: quotas
+    that fill early, late or never, min_num 0, overlapping thresholds (a proposal taken twice), more than one 1024-proposal
+    chunk, and a degenerate proposal before / after the point where the walk stops (AssertionError only if visited)."""
+    from vision_amd import rcnn_utils
+    rng = np.random.default_rng(21)
+    bbox = [40, 30, 120, 90]
+    for n in (1, 7, 1024, 1025, 5000):
+        xy = rng.integers(0, 160, (n, 2)); wh = rng.integers(4, 140, (n, 2))
+        rects = np.concatenate([xy, wh], 1)
+        rects[rng.integers(0, n, max(n // 8, 1))] = [45, 35, 110, 85]          # some clear positives
+        for min_num, pos, neg, mult, full in ((5, 0.1, 0.1, 2, False), (64, 0.5, 0.1, 1, True), (0, 0.1, 0.1, 2, False),
+                                              (3, 0.1, 0.3, 2, False), (100000, 0.1, 0.1, 2, False), (1, 0.5, 0.1, 1, True)):
+            want = oracle.label_proposals(rects, bbox, 3, min_num, pos, neg, mult, full)
+            got = rcnn_utils.label_proposals(rects, bbox, 3, min_num, pos, neg, mult, full)
+            assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2]) and np.array_equal(got[1], want[1]), (n, min_num, pos, neg)
+    # a zero-width proposal: the reference asserts inside get_iou when the walk reaches it, and never sees it after the stop
+    rects = np.tile(np.array([[45, 35, 110, 85], [0, 0, 5, 5]]), (40, 1))       # alternating positive / negative
+    want = oracle.label_proposals(rects, bbox, 3, 2, 0.1, 0.1, 2)
+    bad_late = rects.copy(); bad_late[60] = [10, 10, 0, 5]
+    got = rcnn_utils.label_proposals(bad_late, bbox, 3, 2, 0.1, 0.1, 2)
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[2], want[2])
+    bad_early = rects.copy(); bad_early[3] = [10, 10, 0, 5]
+    with pytest.raises(AssertionError):
+        oracle.label_proposals(bad_early, bbox, 3, 2, 0.1, 0.1, 2)
+    with pytest.raises(AssertionError):
+        rcnn_utils.label_proposals(bad_early, bbox, 3, 2, 0.1, 0.1, 2)
+
+
 def test_label_proposals_golden(va, golden):
     from vision_amd import rcnn_utils
     g = golden("do_ss_quota")

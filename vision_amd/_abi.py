@@ -69,6 +69,7 @@ SIGNATURES = {
     "dg_kmeans_iou_run_sharded": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _sz, C.c_int, _vp]),
     "dg_rcnn_calcul_f32": (C.c_int, [_vp, _i64, _vp, _vp, _vp]),
     "dg_rcnn_decode_f32": (C.c_int, [_vp, _vp, _i64, C.c_int, _vp, _vp]),
+    "dg_rcnn_label_quota_f64": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _f64, _f64, _i32, _vp, _vp, _vp, _vp]),
     "dg_yolo1_encode_f64": (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
     "dg_yolo1_loss_workspace_bytes": (C.c_size_t, [_i64]),
     "dg_yolo1_loss_f32": (C.c_int, [_vp, _vp, _i64, _i64, C.c_int, _vp, _vp, _vp, C.c_size_t, _vp]),

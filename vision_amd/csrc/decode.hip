@@ -482,6 +482,105 @@ extern "C" int dg_rcnn_decode_f32(const int32_t *p_rect, const float *tset, int6
     return DG_OK;
 }
 
+// ---------------------------------------------------------------- proposal labelling: the quota walk of do_ss ("next" row 4)
+// rcnn/rcnn.py:35-65 (rcnn/fast_rcnn.py:123-155): proposals are visited in order; one with iou >= pos_thr is taken as a
+// positive while fewer than min_num positives have been taken, one with iou < neg_thr as a negative while fewer than
+// quota_neg have; the first visit that finds a quota already full raises that quota's flag, and the walk stops after the
+// visit at which both flags are up.  As a scan: with cp[e] / cn[e] the numbers of candidates before e, e is taken as a
+// positive iff cp[e] < min_num, the positive flag goes up at the first e with cp[e] >= min_num (likewise cn / quota_neg),
+// the last visit is e* = the later of the two (n-1 if a flag never goes up), and the output slot of a selection is the
+// number of selections before it.  One 1024-thread workgroup, two passes over the ious (ballot + wave prefix).
+// out[0] = selections, out[1] = status: bit 0 a visited proposal carries an assert flag (rcnn/utils.py:51-54,65-66),
+// bit 1 / bit 2 the positive / negative quota flag went up.
+#define LQ_T 1024
+__global__ __launch_bounds__(LQ_T) void k_rcnn_label_quota(const double *__restrict__ iou, const int32_t *__restrict__ flags, int64_t n,
+                                                           long long min_num, long long quota_neg, double pos_thr, double neg_thr,
+                                                           int32_t label, int32_t *__restrict__ sel, int32_t *__restrict__ lab,
+                                                           int32_t *__restrict__ out)
+{
+    __shared__ int wcnt[2][LQ_T / 64];
+    __shared__ long long s_ef, s_eb;
+    __shared__ int s_bad;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) { s_ef = n; s_eb = n; s_bad = 0; }           // n = "never"
+    __syncthreads();
+    const u64 below = (1ull << lane) - 1ull;
+    // one chunk of the scan: candidates before element e inside the chunk (exclusive), chunk totals in tp / tn
+    auto chunk_scan = [&](int64_t e, bool &p, bool &q, long long &cpe, long long &cne, int &tp, int &tn) {
+        const double v = (e < n) ? iou[e] : 0.0;
+        p = e < n && v >= pos_thr;
+        q = e < n && v < neg_thr;
+        const u64 bp = __ballot(p), bq = __ballot(q);
+        if (lane == 0) { wcnt[0][wave] = __builtin_popcountll(bp); wcnt[1][wave] = __builtin_popcountll(bq); }
+        __syncthreads();
+        int wp = 0, wq = 0;
+        tp = 0; tn = 0;
+#pragma unroll
+        for (int w = 0; w < LQ_T / 64; ++w) {
+            const int a = wcnt[0][w], b = wcnt[1][w];
+            if (w < wave) { wp += a; wq += b; }
+            tp += a; tn += b;
+        }
+        __syncthreads();
+        cpe = wp + __builtin_popcountll(bp & below);
+        cne = wq + __builtin_popcountll(bq & below);
+    };
+    // pass 1: where the two flags go up
+    long long base_p = 0, base_n = 0;
+    for (int64_t c0 = 0; c0 < n; c0 += LQ_T) {
+        bool p, q; long long cpe, cne; int tp, tn;
+        const int64_t e = c0 + tid;
+        chunk_scan(e, p, q, cpe, cne, tp, tn);
+        if (e < n) {
+            const u64 f = __ballot(base_p + cpe >= min_num), b = __ballot(base_n + cne >= quota_neg);
+            if (f && lane == __builtin_ctzll(f)) atomicMin((unsigned long long *)&s_ef, (unsigned long long)e);
+            if (b && lane == __builtin_ctzll(b)) atomicMin((unsigned long long *)&s_eb, (unsigned long long)e);
+        }
+        base_p += tp; base_n += tn;
+        __syncthreads();
+        if (s_ef < n && s_eb < n) break;                      // uniform: both known, later chunks are never visited
+    }
+    __syncthreads();
+    const long long ef = s_ef, eb = s_eb;
+    const int64_t elast = (ef < n && eb < n) ? (ef > eb ? ef : eb) : n - 1;
+    // pass 2: the selections of the visited proposals
+    base_p = 0; base_n = 0;
+    long long total = 0;
+    for (int64_t c0 = 0; c0 <= elast; c0 += LQ_T) {
+        bool p, q; long long cpe, cne; int tp, tn;
+        const int64_t e = c0 + tid;
+        chunk_scan(e, p, q, cpe, cne, tp, tn);
+        if (e <= elast) {
+            const long long cp = base_p + cpe, cn = base_n + cne;
+            if (flags[e] != 0) s_bad = 1;
+            const bool tp_ = p && cp < min_num, tn_ = q && cn < quota_neg;
+            const long long slot = (cp < min_num ? cp : min_num) + (cn < quota_neg ? cn : quota_neg);
+            if (tp_) { sel[slot] = (int32_t)e; lab[slot] = label; }
+            if (tn_) { sel[slot + (tp_ ? 1 : 0)] = (int32_t)e; lab[slot + (tp_ ? 1 : 0)] = 0; }
+            if (e == elast) total = slot + (tp_ ? 1 : 0) + (tn_ ? 1 : 0);
+        }
+        base_p += tp; base_n += tn;
+    }
+    __syncthreads();
+    if (n > 0 && (int64_t)tid == (elast % LQ_T)) {
+        out[0] = (int32_t)total;
+        out[1] = (s_bad ? 1 : 0) | (ef < n ? 2 : 0) | (eb < n ? 4 : 0);
+    }
+    if (n == 0 && tid == 0) { out[0] = 0; out[1] = 0; }
+}
+
+extern "C" int dg_rcnn_label_quota_f64(const double *iou, const int32_t *flags, int64_t n, int64_t min_num, int64_t quota_neg,
+                                       double pos_thr, double neg_thr, int32_t label, int32_t *sel, int32_t *lab, int32_t *out,
+                                       dg_stream_t s)
+{
+    DG_REQUIRE(n >= 0 && n <= 0x7fffffff && min_num >= 0 && quota_neg >= 0, "rcnn_label_quota: bad size");
+    DG_REQUIRE(out && (n == 0 || (iou && flags && sel && lab)), "rcnn_label_quota: null pointer");
+    hipLaunchKernelGGL(k_rcnn_label_quota, dim3(1), dim3(LQ_T), 0, (hipStream_t)s, iou, flags, n, (long long)min_num, (long long)quota_neg,
+                       pos_thr, neg_thr, label, sel, lab, out);
+    DG_CHECK_LAUNCH("k_rcnn_label_quota");
+    return DG_OK;
+}
+
 // ---------------------------------------------------------------- YOLOv1 target encoder ("next" row 4)
 // encode(bb,label,num_classes): yolo/yolo_v1/modules.py:151-174, float64 like NumPy.  bb = {left, top, w, h} relative
 // to the image; the object's cell gets [x_cell, y_cell, w, h, 1] in both box slots and a one-hot class.

@@ -60,25 +60,21 @@ def label_proposals(rects_xywh, bbox_xywh, label, min_num, pos_thr=0.1, neg_thr=
     rois = rects.copy()
     rois[:, 2] += rois[:, 0]
     rois[:, 3] += rois[:, 1]
-    ious, flags = iou_many(rois, grt) if len(rois) else (np.zeros(0), np.zeros(0, np.int32))
-    count_t = count_f = 0
-    fflag = bflag = 0
-    sel, labels = [], []
-    for e in range(len(rois)):
-        assert flags[e] == 0, "get_iou: degenerate box or iou outside [0,1]"
-        iou = ious[e]
-        if count_t < min_num:
-            if iou >= pos_thr:
-                sel.append(e); labels.append(int(label)); count_t += 1
-        else:
-            fflag = 1
-        if count_f < min_num * neg_quota_mult:
-            if iou < neg_thr:
-                sel.append(e); labels.append(0); count_f += 1
-        else:
-            bflag = 1
-        if fflag == 1 and bflag == 1:
-            break
-    if require_full and (fflag == 0 or bflag == 0):
+    n = len(rois)
+    if n == 0:
         return np.zeros((0, 4), np.int_), grt, np.zeros((0,), np.int_)
-    return rois[sel].astype(np.int_).reshape(-1, 4), grt, np.array(labels, dtype=np.int_)
+    # IoU of every proposal against the ground truth, then the ordered quota walk, both on the GPU (dg_rcnn_label_quota_f64)
+    iou, flags = ops.iou_rois_vs_gt(rois.astype(np.float64), grt)
+    dev = iou.device
+    sel = torch.empty(2 * n, dtype=torch.int32, device=dev)
+    lab = torch.empty(2 * n, dtype=torch.int32, device=dev)
+    out = torch.zeros(2, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(load().dg_rcnn_label_quota_f64(ptr(iou), ptr(flags), n, int(min_num), int(min_num * neg_quota_mult), float(pos_thr),
+                                             float(neg_thr), int(label), ptr(sel), ptr(lab), ptr(out), stream_ptr(dev)))
+    count, status = (int(v) for v in out.cpu())
+    assert not (status & 1), "get_iou: degenerate box or iou outside [0,1]"
+    if require_full and (status & 6) != 6:
+        return np.zeros((0, 4), np.int_), grt, np.zeros((0,), np.int_)
+    sel, labels = sel[:count].cpu().numpy(), lab[:count].cpu().numpy()
+    return rois[sel].astype(np.int_).reshape(-1, 4), grt, labels.astype(np.int_)
