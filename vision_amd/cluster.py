@@ -308,8 +308,10 @@ class kmean:
             cur.wait_stream(self._side)
         else:
             be.run_sharded(comm, slot0, count, use_graph)
-        st = comm.graph_state()
-        self.graph_state = {2: "captured", 1: "armed", 0: "eager: graph capture disabled"}.get(st, "eager: " + _abi.last_error())
+        if not use_graph:
+            self.graph_state = "eager: graph capture disabled"
+        else:
+            self.graph_state = {2: "captured", 1: "armed"}.get(comm.graph_state(), "eager: " + _abi.last_error())
 
     def _run_iters(self, slot0, count):
         """`count` Lloyd iterations, asynchronous on the current stream (history slots slot0..slot0+count-1)."""
