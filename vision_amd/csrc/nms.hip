@@ -12,6 +12,7 @@
 //            OR-ed into per-thread `removed` words.  Implements the reference's `numel()>1`
 //            quirk exactly.
 #include "common.hpp"
+#include <type_traits>
 #include <string.h>
 #include <math.h>
 
@@ -166,9 +167,10 @@ __global__ __launch_bounds__(256) void k_nms_gather(const float4 *__restrict__ b
 }
 
 // ---------------------------------------------------------------- mask
-// grid: x = column tile (MT_WORDS = 32 words = 2048 columns), y = 64-row block, z = image.  256 threads; a wave
-// owns 8 of the tile's 32 word-columns (32-word tiles: 17 KB of LDS, eight workgroups = 8 waves per SIMD on a CU;
-// with 64-word tiles and four workgroups per CU the 64k mask took 1.31 ms instead of 1.20).  One lane owns one column; the row box is an LDS broadcast.
+// grid: x = column tile (MTW = 32 words = 2048 columns; 8 words for small launches), y = 64-row block, z = image.
+// 256 threads; a wave owns MTW / 4 of the tile's word-columns (32-word tiles: 17 KB of LDS, eight workgroups = 8 waves per
+// SIMD on a CU; with 64-word tiles and four workgroups per CU the 64k mask took 1.31 ms instead of 1.16-1.20).  One lane
+// owns one column; the row box is an LDS broadcast.
 //
 // The test !(inter/den < thr) is done without the division.  With p = the float below thr and
 // m = (p+thr)/2, a correctly rounded quotient is < thr exactly when the real quotient is below m
@@ -182,7 +184,6 @@ __global__ __launch_bounds__(256) void k_nms_gather(const float4 *__restrict__ b
 //
 // Besides the mask words, every row gets a summary: bit w of rsum[row][t] says word 64t+w is non-zero.
 // The reduce phase walks summaries, so it touches only the non-zero words of the rows it keeps.
-#define MT_WORDS 32
 // nms_suppressed<TIE_EVEN>(inter, den, mid): common.hpp
 
 // v_min/v_max as such: fminf/fmaxf would first canonicalise every operand (one more VALU op each); with
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(256) void k_nms_gather(const float4 *__restrict__ b
 __device__ __forceinline__ float vmin(float a, float b) { float o; asm("v_min_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b)); return o; }
 __device__ __forceinline__ float vmax(float a, float b) { float o; asm("v_max_f32 %0, %1, %2" : "=v"(o) : "v"(a), "v"(b)); return o; }
 
-template <bool TIE_EVEN>
+template <bool TIE_EVEN, int MTW>
 __global__ __launch_bounds__(256, 4) void k_nms_mask(const float *__restrict__ sx1, const float *__restrict__ sy1,
                                                   const float *__restrict__ sx2, const float *__restrict__ sy2,
                                                   const float *__restrict__ sarea, const int32_t *__restrict__ counts,
@@ -199,12 +200,12 @@ __global__ __launch_bounds__(256, 4) void k_nms_mask(const float *__restrict__ s
 {
     __shared__ float4 rbox[64];
     __shared__ float rarea[64];
-    __shared__ u64 tile[64][MT_WORDS + 1];
+    __shared__ u64 tile[64][MTW + 1];
     const int img = blockIdx.z;
     const int n = counts ? counts[img] : (int)nmax;
     const int ib = blockIdx.y;
-    const int jt = blockIdx.x, jb0 = jt * MT_WORDS;
-    if (ib * 64 >= n || (int64_t)jb0 * 64 >= n || jb0 + MT_WORDS <= ib) return;   // below the diagonal / outside
+    const int jt = blockIdx.x, jb0 = jt * MTW;
+    if (ib * 64 >= n || (int64_t)jb0 * 64 >= n || jb0 + MTW <= ib) return;   // below the diagonal / outside
     const int64_t o = (int64_t)img * Np;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 64) {
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(256, 4) void k_nms_mask(const float *__restrict__ s
     __syncthreads();
     const bool rowbad = __ballot(!(rarea[lane] < INFINITY)) != 0ull;
 #pragma unroll 1
-    for (int q = 0; q < MT_WORDS / 4; ++q) {
+    for (int q = 0; q < MTW / 4; ++q) {
         const int wi = wave + 4 * q;
         const int jb = jb0 + wi;
         asm volatile("" ::: "memory");                             // keep the row reads inside the loop, not in 320 registers
@@ -266,20 +267,25 @@ __global__ __launch_bounds__(256, 4) void k_nms_mask(const float *__restrict__ s
     if (tid < 64) {
         u32 sbits = 0;
 #pragma unroll 8
-        for (int w = 0; w < MT_WORDS; ++w) sbits |= (u32)(tile[tid][w] != 0ull) << w;
-        // half of the row's summary word (little endian: tile jt even = low half); the even tile writes the whole word
-        // when the odd one has no columns (it returns at the top, or is not in the grid)
-        const int64_t si = (o + (int64_t)ib * 64 + tid) * SW;
-        if ((jt & 1) == 0 && (int64_t)(jb0 + MT_WORDS) * 64 >= n) rsum[si + (jt >> 1)] = (u64)sbits;
-        else reinterpret_cast<u32 *>(rsum)[si * 2 + jt] = sbits;
+        for (int w = 0; w < MTW; ++w) sbits |= (u32)(tile[tid][w] != 0ull) << w;
+        // this tile's part of the row's summary word (little endian: 64 / MTW parts of MTW bits); the last tile that has
+        // columns also zeroes the parts after its own (those tiles return at the top, or are not in the grid)
+        typedef typename std::conditional<MTW == 32, u32, unsigned char>::type part_t;
+        constexpr int PER = 64 / MTW;
+        part_t *ps = reinterpret_cast<part_t *>(rsum + (o + (int64_t)ib * 64 + tid) * SW + jt / PER);
+        const int pi = jt % PER;
+        ps[pi] = (part_t)sbits;
+        if ((int64_t)(jb0 + MTW) * 64 >= n)
+            for (int z = pi + 1; z < PER; ++z) ps[z] = 0;
     }
-    // 64 rows x 32 words out, 256 contiguous bytes per row, two rows per wave pass
+    // 64 rows x MTW words out, MTW * 8 contiguous bytes per row, 64 / MTW rows per wave pass
     u64 *mo = mask + (o + (int64_t)ib * 64) * W + jb0;
-    const int col = lane & 31, half = lane >> 5;
+    constexpr int RPP = 64 / MTW;
+    const int col = lane % MTW, sub = lane / MTW;
     if (jb0 + col < W) {
-#pragma unroll 4
-        for (int p = 0; p < 8; ++p) {
-            const int row = (wave + 4 * p) * 2 + half;
+#pragma unroll
+        for (int p = 0; p < MTW / 4; ++p) {
+            const int row = (wave + 4 * p) * RPP + sub;
             mo[(int64_t)row * W + col] = tile[row][col];
         }
     }
@@ -923,13 +929,16 @@ extern "C" int dg_nms_phase_mask(const int32_t *counts, int64_t batch, int64_t n
     const bool tie_even = dg_nms_threshold_mid(threshold, &mid);
     const int fast_ok = threshold >= 0x1p-20f && threshold < INFINITY;
     const float below = fast_ok ? nextafterf(threshold, -INFINITY) : threshold;
-    dim3 grid((unsigned)dg_cdiv(w.W, MT_WORDS), (unsigned)w.W, (unsigned)batch);
-    if (tie_even)
-        hipLaunchKernelGGL(k_nms_mask<true>, grid, dim3(256), 0, (hipStream_t)s, w.x1, w.y1, w.x2, w.y2, w.area, counts, nmax, w.Np,
-                           w.W, w.SW, threshold, below, mid, fast_ok, w.mask, w.rsum);
-    else
-        hipLaunchKernelGGL(k_nms_mask<false>, grid, dim3(256), 0, (hipStream_t)s, w.x1, w.y1, w.x2, w.y2, w.area, counts, nmax, w.Np,
-                           w.W, w.SW, threshold, below, mid, fast_ok, w.mask, w.rsum);
+    // 32-word tiles; small launches (one image of a few thousand boxes) take 8-word tiles so that more than a handful of
+    // workgroups exist: 2000 boxes = 32 row blocks x 1 tile would keep 32 of 256 CUs busy
+    const bool small = dg_cdiv(w.W, 32) * w.W * batch < 512;
+#define MASK_LAUNCH(TE, MTW)                                                                                                     \
+    hipLaunchKernelGGL((k_nms_mask<TE, MTW>), dim3((unsigned)dg_cdiv(w.W, MTW), (unsigned)w.W, (unsigned)batch), dim3(256), 0,   \
+                       (hipStream_t)s, w.x1, w.y1, w.x2, w.y2, w.area, counts, nmax, w.Np, w.W, w.SW, threshold, below, mid,     \
+                       fast_ok, w.mask, w.rsum)
+    if (tie_even) { if (small) MASK_LAUNCH(true, 8); else MASK_LAUNCH(true, 32); }
+    else { if (small) MASK_LAUNCH(false, 8); else MASK_LAUNCH(false, 32); }
+#undef MASK_LAUNCH
     DG_CHECK_LAUNCH("k_nms_mask");
     return DG_OK;
 }
