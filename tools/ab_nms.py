@@ -1,6 +1,6 @@
 """A/B of the 64k NMS phases (mask, reduce) between builds of the library, in ONE process on the SAME workspace, launches
 interleaved:  python tools/ab_nms.py vision_amd/libdetgeom.so vision_amd/libexp_x.so [...]
-AB_N (65536), AB_DENSE (0/1: wh U(0.05,0.3) instead of U(0.005,0.05)), AB_THR (0.5).  Checks that the keep lists agree."""
+AB_N (65536), AB_FRCNN (1: Fast R-CNN proposals), AB_DENSE (0/1: wh U(0.05,0.3) instead of U(0.005,0.05)), AB_THR (0.5).  Checks that the keep lists agree."""
 import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, ".")
@@ -10,7 +10,10 @@ from tools import workloads as wl
 n = int(os.environ.get("AB_N", "65536")); dense = os.environ.get("AB_DENSE", "0") == "1"; thr = float(os.environ.get("AB_THR", "0.5"))
 it = int(os.environ.get("AB_IT", "20")); rounds = int(os.environ.get("AB_ROUNDS", "7"))
 dev = torch.device("cuda", 0)
-b, s = wl.stress_boxes(0, n, dense=dense)
+if os.environ.get("AB_FRCNN", "0") == "1":                  # config 1's proposals (AB_N = 2000) instead of the 64k stress boxes
+    b, s = wl.frcnn_proposals(1, n)
+else:
+    b, s = wl.stress_boxes(0, n, dense=dense)
 boxes, scores = torch.from_numpy(b).to(dev), torch.from_numpy(s).to(dev)
 base = abi.load()
 wsb = base.dg_nms_workspace_bytes(1, n)

@@ -705,6 +705,74 @@ __global__ __launch_bounds__(256) void k_nms_csr_fill_wave(const u64 *__restrict
     }
 }
 
+// count + scan + fill in ONE launch for images of at most 64 blocks (W <= 64: one summary word per row, at most four rows per
+// thread): a wave's 64 consecutive rows are one block, so block counts need no atomics and a block's run is filled in row
+// order from the wave's prefix sums.  One 1024-thread workgroup per image (three launches of a few microseconds each
+// otherwise: a third of a single 2000-box image's NMS); with few images gridDim.y workgroups share an image's blocks for the
+// fill (each counts and scans for itself: 16 KB of summaries), since one workgroup alone fills a dense image's run slowly.
+__global__ __launch_bounds__(1024) void k_nms_csr_build_small(const u64 *__restrict__ mask, const u64 *__restrict__ rsum,
+                                                              const int32_t *__restrict__ counts, int64_t nmax, int64_t Np, int64_t W,
+                                                              int64_t ecap_fit, int64_t ecap, int32_t *__restrict__ boff,
+                                                              int32_t *__restrict__ cflag, u32 *__restrict__ ekey, u64 *__restrict__ eval)
+{
+    __shared__ int s_cnt[64], s_off[65];
+    __shared__ int s_fits;
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int n = counts ? counts[img] : (int)nmax;
+    const int nb = (n + 63) >> 6;                                // <= 64
+    u64 bits[4];
+    int cnt[4], incl[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int row = tid + 1024 * k, ib = row >> 6;
+        bits[k] = (row < n) ? csr_live_bits(rsum[((int64_t)img * Np + row) * 1], 0, ib) : 0ull;
+        cnt[k] = __builtin_popcountll(bits[k]);
+        int in = cnt[k];
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(in, d, 64);
+            if (lane >= d) in += up;
+        }
+        incl[k] = in;
+        if (lane == 63 && ib < 64) s_cnt[ib] = in;               // every block is visited by exactly one wave
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int v = (tid < nb) ? s_cnt[tid] : 0;
+        int in = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const int up = __shfl_up(in, d, 64);
+            if (lane >= d) in += up;
+        }
+        const int total = __shfl(in, 63, 64);
+        const bool fits = (int64_t)total <= ecap_fit;
+        if (tid < nb) s_off[tid] = in - v;
+        if (tid == 0) s_fits = fits;
+        if (blockIdx.y == 0) {                                   // the parts count and scan alike; part 0 publishes
+            if (tid < nb) boff[(int64_t)img * (W + 1) + tid] = fits ? in - v : 0;
+            if (tid == 0) { boff[(int64_t)img * (W + 1) + nb] = fits ? total : 0; cflag[img] = fits ? 1 : 0; }
+        }
+    }
+    __syncthreads();
+    if (!s_fits) return;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int row = tid + 1024 * k, ib = row >> 6;
+        if (row >= n || !bits[k] || (ib % (int)gridDim.y) != (int)blockIdx.y) continue;     // this part's blocks
+        int64_t pos = (int64_t)img * (ecap + CSR_SLACK) + s_off[ib] + (incl[k] - cnt[k]);
+        const u64 *mrow = mask + ((int64_t)img * Np + row) * W;
+        u64 b = bits[k];
+        while (b) {
+            const int w = __builtin_ctzll(b);
+            b &= b - 1;
+            ekey[pos] = ((u32)(row & 63) << 16) | (u32)w;
+            eval[pos] = mrow[w];
+            ++pos;
+        }
+    }
+}
+
 __global__ __launch_bounds__(1024) void k_nms_reduce_csr(const u64 *__restrict__ mask, const int32_t *__restrict__ order,
                                                          const int32_t *__restrict__ counts, int64_t nmax, int64_t Np, int64_t W,
                                                          int64_t ecap, const int32_t *__restrict__ cflag, const int32_t *__restrict__ boff,
@@ -958,20 +1026,26 @@ extern "C" int dg_nms_phase_reduce(const int32_t *counts, int64_t batch, int64_t
     if (w.W < NMS_CSR_MIN_W) RED(64, 1);
     else if (w.W <= 1024) {
         // compact the mask, then the LDS-fed reduce; an image whose entries do not fit falls to the summary-driven kernel
-        hipLaunchKernelGGL(k_nms_csr_count, dim3((unsigned)(w.Np / 256 + (w.Np % 256 != 0)), (unsigned)batch), dim3(256), 0, st, w.rsum,
-                           counts, nmax, w.Np, w.W, w.SW, w.bcnt);
         // DG_NMS_FORCE_FALLBACK=1 (tests): no image "fits" the compact form, every one takes the dense-mask reduce
         const bool force_fb = getenv("DG_NMS_FORCE_FALLBACK") && atoi(getenv("DG_NMS_FORCE_FALLBACK")) != 0;
-        hipLaunchKernelGGL(k_nms_csr_scan, dim3((unsigned)batch), dim3(1024), 0, st, w.bcnt, counts, nmax, w.W, force_fb ? (int64_t)-1 : w.ecap,
-                           w.boff, w.cursor, w.cflag);
-        if ((w.SW & (w.SW - 1)) == 0 && w.SW <= 64) {
-            int sh = 0;
-            while ((1ll << sh) < w.SW) ++sh;
-            hipLaunchKernelGGL(k_nms_csr_fill_wave, dim3((unsigned)dg_cdiv(w.Np * w.SW, 256), (unsigned)batch), dim3(256), 0, st, w.mask,
-                               w.rsum, counts, nmax, w.Np, w.W, w.SW, sh, w.ecap, w.cflag, w.cursor, w.ekey, w.eval);
+        const int64_t ecap_fit = force_fb ? (int64_t)-1 : w.ecap;
+        if (w.W <= 64) {
+            hipLaunchKernelGGL(k_nms_csr_build_small, dim3((unsigned)batch, batch < 32 ? 8u : 1u), dim3(1024), 0, st, w.mask, w.rsum, counts, nmax, w.Np, w.W,
+                               ecap_fit, w.ecap, w.boff, w.cflag, w.ekey, w.eval);
         } else {
-            hipLaunchKernelGGL(k_nms_csr_fill, dim3((unsigned)dg_cdiv(w.Np * w.SW, 256), (unsigned)batch), dim3(256), 0, st, w.mask, w.rsum,
-                               counts, nmax, w.Np, w.W, w.SW, w.ecap, w.cflag, w.cursor, w.ekey, w.eval);
+            hipLaunchKernelGGL(k_nms_csr_count, dim3((unsigned)(w.Np / 256 + (w.Np % 256 != 0)), (unsigned)batch), dim3(256), 0, st, w.rsum,
+                               counts, nmax, w.Np, w.W, w.SW, w.bcnt);
+            hipLaunchKernelGGL(k_nms_csr_scan, dim3((unsigned)batch), dim3(1024), 0, st, w.bcnt, counts, nmax, w.W, ecap_fit, w.boff, w.cursor,
+                               w.cflag);
+            if ((w.SW & (w.SW - 1)) == 0 && w.SW <= 64) {
+                int sh = 0;
+                while ((1ll << sh) < w.SW) ++sh;
+                hipLaunchKernelGGL(k_nms_csr_fill_wave, dim3((unsigned)dg_cdiv(w.Np * w.SW, 256), (unsigned)batch), dim3(256), 0, st, w.mask,
+                                   w.rsum, counts, nmax, w.Np, w.W, w.SW, sh, w.ecap, w.cflag, w.cursor, w.ekey, w.eval);
+            } else {
+                hipLaunchKernelGGL(k_nms_csr_fill, dim3((unsigned)dg_cdiv(w.Np * w.SW, 256), (unsigned)batch), dim3(256), 0, st, w.mask, w.rsum,
+                                   counts, nmax, w.Np, w.W, w.SW, w.ecap, w.cflag, w.cursor, w.ekey, w.eval);
+            }
         }
         hipLaunchKernelGGL(k_nms_reduce_csr, dim3((unsigned)batch), dim3(1024), 0, st, w.mask, w.order, counts, nmax, w.Np, w.W, w.ecap,
                            w.cflag, w.boff, w.ekey, w.eval, quirk_drop_last, keep, keep_count);
