@@ -6,7 +6,7 @@
  * Plain C, scalar, single-threaded, compiled with -O2 -ffp-contract=off so every
  * float op is one IEEE-754 operation in the order the reference's torch/numpy
  * expression evaluates it.  Each function cites the reference lines it follows
- * (paths relative to the reference repo).  Pinned against tests/golden/*.npz,
+ * (paths relative to the reference repo).  Pinned against the .npz files of tests/golden,
  * which were produced by executing the reference's own function bodies
  * (oracle/gen_golden.py).  The 1-IoU k-means has NO reference counterpart
  * ("parity unpinned"): its spec is stated at orc_kmeans_*.
@@ -284,6 +284,7 @@ int orc_roipool_bwd2_f32(const float *grad_out, const int32_t *argmax, int64_t B
                          const double *rois, const int64_t *roi_idx, int64_t n, int PH, int PW, int mode,
                          float *grad_in)
 {
+    (void)B;                                     /* the caller sized (and zeroed) grad_in; roi_idx is trusted as in the reference */
     for (int64_t r = 0; r < n; ++r) {
         int x1, y1, x2, y2;
         int st = orc_roi_window(rois + 4 * r, H, W, &x1, &y1, &x2, &y2);
