@@ -386,14 +386,17 @@ def extra_kmeans(d, n_total=10_000_000, iters=30):
         loops = {}
         for name, comm, graph in (("torch_eager", "torch", "0"), ("so_eager", "so", "0"), ("torch_graph", "torch", "1"), ("so_graph", "so", "1")):
             os.environ["DG_KMEANS_GRAPH"] = graph
-            ke = cluster.kmean(5, 42, comm=comm)
-            ke.fit(shard, init_centers=init, fixed_iters=iters)
-            ke._run_iters(0, iters)                                       # the second run of a chunk is the one that captures
-            sec_e = min(Dist.timed(d, lambda: ke._run_iters(0, iters), 1, 0) for _ in range(5))
-            loops[name] = {"iters_per_s": iters / sec_e, "ms_per_iter": sec_e / iters * 1e3, "state": ke.graph_state, "comm": ke.comm_state}
+            try:                                   # a way that fails alike on every rank (no librccl.so, say) must not cost the others
+                ke = cluster.kmean(5, 42, comm=comm)
+                ke.fit(shard, init_centers=init, fixed_iters=iters)
+                ke._run_iters(0, iters)                                   # the second run of a chunk is the one that captures
+                sec_e = min(Dist.timed(d, lambda: ke._run_iters(0, iters), 1, 0) for _ in range(5))
+                loops[name] = {"iters_per_s": iters / sec_e, "ms_per_iter": sec_e / iters * 1e3, "state": ke.graph_state, "comm": ke.comm_state}
+                ke.close()
+                del ke
+            except Exception as e:  # noqa: BLE001
+                loops[name] = {"error": f"{type(e).__name__}: {e}"}
             PARTIAL["config4_kmeans_10M"] = {"loops": dict(loops), "ranks": d.world, "note": "a later way of issuing the loop did not finish"}
-            ke.close()
-            del ke
         os.environ.pop("DG_KMEANS_GRAPH", None)
     km = cluster.kmean(5, 42, reduce_device="cpu" if d.rehearse else None)   # rehearsal: gloo reduces host tensors
     km.fit(shard, init_centers=init, fixed_iters=iters)     # warm-up (RCCL channels, graph capture); leaves the device state
@@ -406,7 +409,7 @@ def extra_kmeans(d, n_total=10_000_000, iters=30):
          "device_ms_per_iter_this_shard": ms, "iter_hbm_frac": (12.0 * per) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
          "iter_valu_frac": valu_frac("k_kmeans_step", per, ms),
          "centers": km.cluster_centers_.round(6).tolist(), "loops": loops,
-         "best_iters_per_s": max([iters / sec] + [v["iters_per_s"] for v in (loops or {}).values()]),
+         "best_iters_per_s": max([iters / sec] + [v["iters_per_s"] for v in (loops or {}).values() if "iters_per_s" in v]),
          "note": "config 4, strong scaling: 10M boxes sharded; per iteration ONE launch (the centroid update is the prologue of "
                  "the next step) + ONE all-reduce of the 2 KiB partial-sums buffer, issued by the library itself (dg_comm_* / "
                  "dg_kmeans_iou_run_sharded; comm says which path ran; `loops` times the other ways of issuing it, best_iters_per_s the fastest); "
