@@ -468,16 +468,16 @@ __global__ __launch_bounds__(1024) void k_nms_reduce_band(const u64 *__restrict_
             if (S < nsb) {
                 int total = s_total, nk_sb = 0, last_ib = s_last_ib, last_r = s_last_r;
                 u64 last_curb = s_last_curb;
+                u64 dg[BAND_BLOCKS];                          // the eight diagonal words up front: nothing in the chain waits for them
+#pragma unroll
+                for (int bb = 0; bb < BAND_BLOCKS; ++bb) dg[bb] = band[bb * PIPE_ROWS + bb * 64 + lane];
 #pragma unroll
                 for (int bb = 0; bb < BAND_BLOCKS; ++bb) {
                     const int ib = S * BAND_BLOCKS + bb;
                     if (ib < nb) {                            // uniform
                         u64 cur = uniform64(removed[ib]);
                         if (cur != ~0ull) {
-                            u64 wd[PIPE_NEAR];
-#pragma unroll
-                            for (int j = bb; j < PIPE_NEAR; ++j) wd[j] = band[j * PIPE_ROWS + bb * 64 + lane];
-                            const u64 diag = wd[bb];
+                            const u64 diag = dg[bb];
                             u64 curb = cur;
                             int lastact = -1;
                             u64 act = ~cur & uniform64(__ballot(diag != 0ull));
@@ -496,9 +496,32 @@ __global__ __launch_bounds__(1024) void k_nms_reduce_band(const u64 *__restrict_
                                 if (mine) {
                                     keep[total + rank] = (int64_t)s_order[bb * 64 + lane];
                                     klist[S & 1][nk_sb + rank] = ib * 64 + lane;
+                                }
+                                // near words of the kept rows into `removed`.  Several lanes OR-ing into ONE LDS word serialise
+                                // (a ds_or_b64 per word with every kept lane active cost more than the rest of the block), so
+                                // with few kept rows the roles turn: lane = word column, a loop over the kept rows, one atomic
+                                // instruction whose lanes all hit different words
+                                if (nk <= 12) {
+                                    u64 acc = 0, km = kept;
+                                    const bool wlane = lane > bb && lane < PIPE_NEAR;
+                                    while (km) {                 // four independent reads per pass (a repeated row ORs the same bits)
+                                        const int r0 = __builtin_ctzll(km); km &= km - 1;
+                                        const int r1 = km ? __builtin_ctzll(km) : r0; km &= km - 1;
+                                        const int r2 = km ? __builtin_ctzll(km) : r0; km &= km - 1;
+                                        const int r3 = km ? __builtin_ctzll(km) : r0; km &= km - 1;
+                                        if (wlane) {
+                                            const u64 *bw = band + lane * PIPE_ROWS + bb * 64;
+                                            const u64 v0 = bw[r0], v1 = bw[r1], v2 = bw[r2], v3 = bw[r3];
+                                            acc |= (v0 | v1) | (v2 | v3);
+                                        }
+                                    }
+                                    if (wlane && acc) atomicOr((unsigned long long *)&removed[S * BAND_BLOCKS + lane], (unsigned long long)acc);
+                                } else if (mine) {
 #pragma unroll
-                                    for (int j = bb + 1; j < PIPE_NEAR; ++j)
-                                        if (wd[j]) atomicOr((unsigned long long *)&removed[S * BAND_BLOCKS + j], (unsigned long long)wd[j]);
+                                    for (int j = bb + 1; j < PIPE_NEAR; ++j) {
+                                        const u64 wj = band[j * PIPE_ROWS + bb * 64 + lane];
+                                        if (wj) atomicOr((unsigned long long *)&removed[S * BAND_BLOCKS + j], (unsigned long long)wj);
+                                    }
                                 }
                                 const int rl = 63 - __builtin_clzll(kept);
                                 last_ib = ib; last_r = rl; last_curb = (rl == lastact) ? curb : cur;
