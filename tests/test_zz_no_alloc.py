@@ -62,3 +62,37 @@ def test_nms_noalloc_rejects_oversize():
     rc = lib.dg_nms_batched_noalloc_f32(_abi.ptr(t), _abi.ptr(t), None, 1, 20000, 0.5, 1, _abi.ptr(t), _abi.ptr(t), _abi.stream_ptr(dev))
     assert rc == _abi.ENOMEM
     assert "built-in buffer" in _abi.last_error()
+
+
+def test_nms_noalloc_under_graph_capture():
+    """The callers the entry point is for: a HIP graph capture, where hipMalloc is not allowed.  Captured once, replayed
+    on new boxes written into the same buffers; sparse and dense boxes (both reduce kernels)."""
+    from vision_amd import _abi, ops
+    lib = _abi.load()
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    for n, dense, thr in ((2000, False, 0.5), (3000, True, 0.5)):
+        boxes = torch.zeros((1, n, 4), dtype=torch.float32, device=dev)
+        scores = torch.zeros((1, n), dtype=torch.float32, device=dev)
+        keep = torch.zeros((1, n), dtype=torch.int64, device=dev)
+        kc = torch.zeros(1, dtype=torch.int32, device=dev)
+
+        def call():
+            rc = lib.dg_nms_batched_noalloc_f32(_abi.ptr(boxes), _abi.ptr(scores), None, 1, n, thr, 1, _abi.ptr(keep), _abi.ptr(kc),
+                                                _abi.stream_ptr(dev))
+            assert rc == 0, _abi.last_error()
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            call()                                           # first call on the device looks the scratch symbol up: outside capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=side):
+            call()
+        for seed in (5, 6):
+            b, s = wl.stress_boxes(seed, n, dense=dense)
+            boxes.copy_(torch.from_numpy(b)[None]); scores.copy_(torch.from_numpy(s)[None])
+            g.replay()
+            torch.cuda.synchronize()
+            k1, c1 = ops.nms_batched(boxes, scores, None, thr, True)
+            assert int(kc.item()) == int(c1.item())
+            assert torch.equal(keep[0, :int(kc.item())], k1[0, :int(c1.item())])
