@@ -67,7 +67,7 @@ int dg_nms_batched_f32(const float *boxes, const float *scores, const int32_t *c
 /* The same NMS for callers that cannot allocate (code under HIP graph capture, tight serving loops, harnesses that
  * forbid hipMalloc).  NO COUNTERPART IN THE REFERENCE.  The workspace is a file-scope device array inside the library
  * (DG_NMS_NOALLOC_SCRATCH_BYTES per GPU, held until the process ends); the call allocates nothing.  Sizes whose
- * dg_nms_workspace_bytes(batch, nmax) exceeds that (12 images x 2000 boxes or one image of 9,800 boxes still fit) are refused
+ * dg_nms_workspace_bytes(batch, nmax) exceeds that (12 images x 2000 boxes or one image of 9,000 boxes still fit) are refused
  * with DG_ENOMEM and a message that names both figures.
  * All calls on one GPU share that GPU's array: calls that overlap on one GPU (different streams / threads) race. */
 #define DG_NMS_NOALLOC_SCRATCH_BYTES (16u << 20)
@@ -93,6 +93,11 @@ int dg_nms_phase_mask(const int32_t *counts, int64_t batch, int64_t nmax, float 
                       void *ws, size_t ws_bytes, dg_stream_t s);
 int dg_nms_phase_reduce(const int32_t *counts, int64_t batch, int64_t nmax, int quirk_drop_last,
                         int64_t *keep, int32_t *keep_count, void *ws, size_t ws_bytes, dg_stream_t s);
+
+/* diagnostic (synchronous): which path image `img` of the LAST call on this workspace took.  out3 (host):
+ * [0] 0 = pruned pair search (x-bucket band, no N x N mask), 1 = dense mask; [1] 1 = the fixed-point keep-list kernel
+ * finished the image, 0 = a serial reduce did; [2] rounds of the fixed point; [3] suppressing pairs found (4 ints).  No counterpart in the reference. */
+int dg_nms_path_info(const void *ws, size_t ws_bytes, int64_t batch, int64_t nmax, int64_t img, int32_t *out4_host);
 
 /* N2 nms(rects,scores): rcnn/fast_rcnn.py:590-610 -- no suppression there: the rects are ordered by
  * np.argsort(scores)[::-1] (:601) and element 0 is returned (:610).  out_index (device int64) = index of the maximal

@@ -33,6 +33,7 @@ SIGNATURES = {
     "dg_nms_batched_noalloc_f32": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _f32, C.c_int, _vp, _vp, _vp]),
     "dg_nms_per_class_workspace_bytes": (_sz, [_i64, _i64, _i64]),
     "dg_nms_batched_per_class_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, _f32, C.c_int, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dg_nms_path_info": (C.c_int, [_vp, _sz, _i64, _i64, _i64, _vp]),
     "dg_top_score_f64": (C.c_int, [_vp, _i64, _vp, _vp]),
     "dg_nms_phase_sort": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _vp, _sz, _vp]),
     "dg_nms_phase_mask": (C.c_int, [_vp, _i64, _i64, _f32, _vp, _sz, _vp]),

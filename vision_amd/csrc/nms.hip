@@ -19,6 +19,18 @@
 #define SORT_CHUNK 4096  // elements sorted inside LDS (32 KiB of keys)
 #define NMS_CSR_MIN_W 8  // from 8 words (449 boxes) per image on, the reduce runs from the compact mask (k_nms_csr_*)
 
+// per image, 64 bytes: what the pruned path (k_nms_xbucket ...) decided; the dense-mask kernels of an image run iff mode == 1
+struct NmsHdr {
+    float xmin, scale;       // x-bucket of a coordinate: clamp((x - xmin) * scale, 0, XB_G - 1)
+    int32_t mode;            // 0: pruned path (banded pair search in x-bucket order); 1: dense mask
+    int32_t fpdone;          // k_nms_resolve_fp converged and wrote the keep list
+    int32_t rounds;          // rounds it took (diagnostic)
+    int32_t npairs;          // suppressing pairs k_nms_band found (entries of the flat pair list; > ecap: overflow, mode -> 1)
+    int32_t xmin_i, xmax_i;  // min / max of x1 as order-preserving integers (k_nms_gather's atomics)
+    int32_t bad;             // a non-finite box was met
+    int32_t pad[7];
+};
+
 struct NmsWs {
     int64_t Np, W, SW, Np2;
     u64 *keys;
@@ -31,6 +43,14 @@ struct NmsWs {
     int32_t *bcnt, *boff, *cursor, *cflag;
     u32 *ekey;
     u64 *eval;
+    // pruned path (round 3, 64 < W <= 1024): header per image, the boxes in x-bucket order (bbox = corners, bar = {area, rank}),
+    // each box's position in that order, bucket starts, "has a suppressor" bits, diagonal words, two work lists
+    int pruned;              // the layout holds the arrays below
+    struct NmsHdr *hdr;
+    float4 *bbox;
+    float2 *bar;
+    int32_t *pos, *start;
+    u64 *diag;
     size_t total;
 };
 
@@ -62,6 +82,19 @@ static NmsWs nms_layout(int64_t batch, int64_t nmax, void *base)
     w.cflag = (int32_t *)take((size_t)batch * 4);
     w.ekey = (u32 *)take((size_t)batch * (w.ecap + 8) * 4);      // + CSR_SLACK
     w.eval = (u64 *)take((size_t)batch * (w.ecap + 8) * 8);
+    // (the pruned path's work lists -- two of ecap u32 per image -- live in the image's part of `mask`, which that path
+    //  never touches: Np * W * 8 >= 2 * 32 * Np * 4 bytes from W = 32 on)
+    w.pruned = (w.W > 64 && w.W <= 1024) ? 1 : 0;
+    if (w.pruned) {
+        w.hdr = (struct NmsHdr *)take((size_t)batch * 64);
+        w.bbox = (float4 *)take((size_t)batch * w.Np * 16);
+        w.bar = (float2 *)take((size_t)batch * w.Np * 8);
+        w.pos = nullptr;
+        w.start = (int32_t *)take((size_t)batch * 4 * 4352 * 4);         // XB_STRIDE ints each: hist of x1 buckets, of x2 buckets, starts, cursors
+        w.diag = (u64 *)take((size_t)batch * w.Np * 8);
+    } else {
+        w.hdr = nullptr; w.bbox = nullptr; w.bar = nullptr; w.pos = nullptr; w.start = nullptr; w.diag = nullptr;
+    }
     w.total = off;
     return w;
 }
@@ -77,6 +110,10 @@ __device__ __forceinline__ void gather_sorted(const float4 *__restrict__ boxes, 
     area[p] = dg_area(b.x, b.y, b.z, b.w);
     order[p] = idx;
 }
+
+// order-preserving int image of a float (and back): the pruned path's min / max of x1 by integer atomics
+__device__ __forceinline__ int32_t xb_ord(float x) { const int32_t b = __float_as_int(x); return b ^ ((b >> 31) & 0x7fffffff); }
+__device__ __forceinline__ float xb_unord(int32_t o) { return __int_as_float(o ^ ((o >> 31) & 0x7fffffff)); }
 
 // ---------------------------------------------------------------- sort, segments <= 4096
 template <int NP2, int T>
@@ -110,11 +147,16 @@ __global__ __launch_bounds__(T) void k_nms_sort_small(const float4 *__restrict__
 
 // ---------------------------------------------------------------- sort, long segments (global bitonic)
 __global__ __launch_bounds__(256) void k_nms_make_keys(const float *__restrict__ scores, const int32_t *__restrict__ counts,
-                                                       int64_t nmax, int64_t Np2, u64 *__restrict__ keys)
+                                                       int64_t nmax, int64_t Np2, u64 *__restrict__ keys, NmsHdr *__restrict__ hdr,
+                                                       int32_t *__restrict__ xb)
 {
     const int img = blockIdx.y;
     const int n = counts ? counts[img] : (int)nmax;
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (hdr) {                                               // pruned path: reset the image's header and its two bucket histograms
+        if (i == 0) { NmsHdr *h = hdr + img; h->mode = 1; h->fpdone = 0; h->rounds = 0; h->npairs = 0; h->xmin_i = 0x7fffffff; h->xmax_i = (int32_t)0x80000000; h->bad = 0; }
+        for (int64_t j = i; j < 2 * 4352; j += Np2) xb[(int64_t)img * 4 * 4352 + j] = 0;
+    }
     if (i < Np2) keys[(int64_t)img * Np2 + i] = (i < n) ? make_key(scores[(int64_t)img * nmax + i], (u32)i) : ~0ull;
 }
 
@@ -157,13 +199,27 @@ __global__ __launch_bounds__(256) void k_bitonic_global(u64 *__restrict__ keys, 
 
 __global__ __launch_bounds__(256) void k_nms_gather(const float4 *__restrict__ boxes, const u64 *__restrict__ keys,
                                                     const int32_t *__restrict__ counts, int64_t nmax, int64_t Np, int64_t Np2,
-                                                    float *x1, float *y1, float *x2, float *y2, float *area, int32_t *order)
+                                                    float *x1, float *y1, float *x2, float *y2, float *area, int32_t *order,
+                                                    NmsHdr *__restrict__ hdr)
 {
     const int img = blockIdx.y;
     const int n = counts ? counts[img] : (int)nmax;
     int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= Np) return;
+    if (p >= Np) return;                                     // Np is a multiple of 64: whole waves leave
     gather_sorted(boxes + (int64_t)img * nmax, keys[(int64_t)img * Np2 + p], p < n, (int64_t)img * Np + p, x1, y1, x2, y2, area, order);
+    if (hdr) {                                               // pruned path: range of the left edges, non-finite boxes
+        const int64_t q = (int64_t)img * Np + p;
+        const bool valid = p < n;
+        int lo = valid ? xb_ord(x1[q]) : 0x7fffffff, hi = valid ? xb_ord(x1[q]) : (int32_t)0x80000000;
+        int bad = valid && !(area[q] < INFINITY);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { lo = min(lo, __shfl_xor(lo, d, 64)); hi = max(hi, __shfl_xor(hi, d, 64)); bad |= __shfl_xor(bad, d, 64); }
+        if ((threadIdx.x & 63) == 0) {
+            NmsHdr *h = hdr + img;
+            if (lo != 0x7fffffff) { atomicMin(&h->xmin_i, lo); atomicMax(&h->xmax_i, hi); }
+            if (bad) atomicOr(&h->bad, 1);
+        }
+    }
 }
 
 // ---------------------------------------------------------------- mask
@@ -196,12 +252,14 @@ __global__ __launch_bounds__(256, 4) void k_nms_mask(const float *__restrict__ s
                                                   const float *__restrict__ sx2, const float *__restrict__ sy2,
                                                   const float *__restrict__ sarea, const int32_t *__restrict__ counts,
                                                   int64_t nmax, int64_t Np, int64_t W, int64_t SW, float thr, float thr_below,
-                                                  double mid, int fast_ok, u64 *__restrict__ mask, u64 *__restrict__ rsum)
+                                                  double mid, int fast_ok, u64 *__restrict__ mask, u64 *__restrict__ rsum,
+                                                  const NmsHdr *__restrict__ hdr)
 {
     __shared__ float4 rbox[64];
     __shared__ float rarea[64];
     __shared__ u64 tile[64][MTW + 1];
     const int img = blockIdx.z;
+    if (hdr && hdr[img].mode != 1) return;                    // the pruned path does this image
     const int n = counts ? counts[img] : (int)nmax;
     const int ib = blockIdx.y;
     const int jt = blockIdx.x, jb0 = jt * MTW;
@@ -419,8 +477,9 @@ __global__ __launch_bounds__(T) void k_nms_reduce(const u64 *__restrict__ mask, 
 __global__ __launch_bounds__(1024) void k_nms_reduce_band(const u64 *__restrict__ mask, const int32_t *__restrict__ order,
                                                           const int32_t *__restrict__ counts, int64_t nmax, int64_t Np, int64_t W,
                                                           int quirk, int64_t *__restrict__ keep, int32_t *__restrict__ keep_count,
-                                                          const int32_t *__restrict__ cflag)
+                                                          const int32_t *__restrict__ cflag, const NmsHdr *__restrict__ hdr)
 {
+    if (hdr && hdr[blockIdx.x].mode != 1) return;             // the pruned path does this image
     if (cflag && cflag[blockIdx.x]) return;                   // k_nms_reduce_csr does this image
     extern __shared__ u64 nms_lds[];
     u64 *removed = nms_lds, *removed1 = nms_lds + W, *band = nms_lds + 2 * W;      // band: [PIPE_NEAR][PIPE_ROWS]
@@ -606,9 +665,11 @@ __device__ __forceinline__ u64 csr_live_bits(u64 sumword, int s, int ib)   // su
 
 // one wave = the 64 rows of one block: bcnt[block] = number of entries
 __global__ __launch_bounds__(256) void k_nms_csr_count(const u64 *__restrict__ rsum, const int32_t *__restrict__ counts, int64_t nmax,
-                                                       int64_t Np, int64_t W, int64_t SW, int32_t *__restrict__ bcnt)
+                                                       int64_t Np, int64_t W, int64_t SW, int32_t *__restrict__ bcnt,
+                                                       const NmsHdr *__restrict__ hdr)
 {
     const int img = blockIdx.y;
+    if (hdr && hdr[img].mode != 1) return;
     const int n = counts ? counts[img] : (int)nmax;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // row; Np is a multiple of 64
     if (i >= Np) return;
@@ -625,10 +686,11 @@ __global__ __launch_bounds__(256) void k_nms_csr_count(const u64 *__restrict__ r
 // one workgroup per image: exclusive scan of the block counts; cflag = the entries fit
 __global__ __launch_bounds__(1024) void k_nms_csr_scan(const int32_t *__restrict__ bcnt, const int32_t *__restrict__ counts, int64_t nmax,
                                                        int64_t W, int64_t ecap, int32_t *__restrict__ boff, int32_t *__restrict__ cursor,
-                                                       int32_t *__restrict__ cflag)
+                                                       int32_t *__restrict__ cflag, const NmsHdr *__restrict__ hdr)
 {
     __shared__ int64_t sc[1024];
     const int img = blockIdx.x, tid = threadIdx.x;
+    if (hdr && hdr[img].mode != 1) return;
     const int n = counts ? counts[img] : (int)nmax;
     const int nb = (n + 63) >> 6;                                    // <= 1024 here
     const int64_t v = (tid < nb) ? bcnt[(int64_t)img * W + tid] : 0;
@@ -657,9 +719,11 @@ __global__ __launch_bounds__(1024) void k_nms_csr_scan(const int32_t *__restrict
 __global__ __launch_bounds__(256) void k_nms_csr_fill(const u64 *__restrict__ mask, const u64 *__restrict__ rsum,
                                                       const int32_t *__restrict__ counts, int64_t nmax, int64_t Np, int64_t W,
                                                       int64_t SW, int64_t ecap, const int32_t *__restrict__ cflag,
-                                                      int32_t *__restrict__ cursor, u32 *__restrict__ ekey, u64 *__restrict__ eval)
+                                                      int32_t *__restrict__ cursor, u32 *__restrict__ ekey, u64 *__restrict__ eval,
+                                                      const NmsHdr *__restrict__ hdr)
 {
     const int img = blockIdx.y;
+    if (hdr && hdr[img].mode != 1) return;
     if (cflag[img] != 1) return;
     const int n = counts ? counts[img] : (int)nmax;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -690,9 +754,11 @@ __global__ __launch_bounds__(256) void k_nms_csr_fill(const u64 *__restrict__ ma
 __global__ __launch_bounds__(256) void k_nms_csr_fill_wave(const u64 *__restrict__ mask, const u64 *__restrict__ rsum,
                                                            const int32_t *__restrict__ counts, int64_t nmax, int64_t Np, int64_t W,
                                                            int64_t SW, int sw_shift, int64_t ecap, const int32_t *__restrict__ cflag,
-                                                           int32_t *__restrict__ cursor, u32 *__restrict__ ekey, u64 *__restrict__ eval)
+                                                           int32_t *__restrict__ cursor, u32 *__restrict__ ekey, u64 *__restrict__ eval,
+                                                           const NmsHdr *__restrict__ hdr)
 {
     const int img = blockIdx.y;
+    if (hdr && hdr[img].mode != 1) return;
     if (!cflag[img]) return;
     const int n = counts ? counts[img] : (int)nmax;
     const int lane = threadIdx.x & 63;
@@ -796,11 +862,17 @@ __global__ __launch_bounds__(1024) void k_nms_csr_build_small(const u64 *__restr
     }
 }
 
+// SEG (the pruned path's fallback, when k_nms_resolve_fp gave up): a prologue first groups k_nms_band's flat pair list
+// (`ekey` = (lower rank << 16 | higher rank) entries, hdr.npairs of them) into per-block runs -- keys into the image's unused
+// dense-mask memory, values into `eval` -- and builds the diagonal words in diag[]; entries of a block's own word column
+// are skipped by the chain (the diagonal words carry them).
+template <bool SEG>
 __global__ __launch_bounds__(1024) void k_nms_reduce_csr(const u64 *__restrict__ mask, const int32_t *__restrict__ order,
                                                          const int32_t *__restrict__ counts, int64_t nmax, int64_t Np, int64_t W,
                                                          int64_t ecap, const int32_t *__restrict__ cflag, const int32_t *__restrict__ boff,
                                                          const u32 *__restrict__ ekey, const u64 *__restrict__ eval, int quirk,
-                                                         int64_t *__restrict__ keep, int32_t *__restrict__ keep_count)
+                                                         int64_t *__restrict__ keep, int32_t *__restrict__ keep_count,
+                                                         const NmsHdr *__restrict__ hdr, const u64 *__restrict__ diag)
 {
     __shared__ u64 remv[1024];
     __shared__ __attribute__((aligned(16))) u64 s_val[2][CSR_LDS_ENTRIES];
@@ -809,13 +881,20 @@ __global__ __launch_bounds__(1024) void k_nms_reduce_csr(const u64 *__restrict__
     __shared__ int32_t s_order[2][64];
     __shared__ int s_len[2], s_new[2];
     __shared__ int32_t s_boff[1025];                          // block offsets: read every iteration, keep them out of the memory path
+    __shared__ int32_t s_blen[1024];
     const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (cflag[img] != 1) return;                              // too dense: k_nms_reduce_band does this image
+    if (SEG) {
+        if (!(hdr[img].mode == 0 && hdr[img].fpdone == 0)) return;   // only what the fixed-point kernel left undone
+    } else {
+        if (hdr && hdr[img].mode != 1) return;                // the pruned path does this image
+        if (cflag[img] != 1) return;                          // too dense: k_nms_reduce_band does this image
+    }
     const int n = counts ? counts[img] : (int)nmax;
     mask += (int64_t)img * Np * W;
+    if (SEG) diag += (int64_t)img * Np;
     order += (int64_t)img * Np;
     keep += (int64_t)img * nmax;
-    boff += (int64_t)img * (W + 1);
+    if (!SEG) boff += (int64_t)img * (W + 1);
     ekey += (int64_t)img * (ecap + CSR_SLACK);
     eval += (int64_t)img * (ecap + CSR_SLACK);
     const int nb = (n + 63) >> 6;
@@ -823,7 +902,43 @@ __global__ __launch_bounds__(1024) void k_nms_reduce_csr(const u64 *__restrict__
         const int64_t base = (int64_t)w * 64;
         remv[w] = (base >= n) ? ~0ull : ((n - base >= 64) ? 0ull : (~0ull << (n - base)));
     }
-    for (int w = tid; w <= nb; w += 1024) s_boff[w] = boff[w];
+    if (SEG) {
+        // group the flat pair list by the lower rank's block: count, scan, scatter (one workgroup; this is the rare path)
+        __shared__ int32_t s_cur[1024];
+        __shared__ int s_wsum[16];
+        u32 *rkey = (u32 *)const_cast<u64 *>(mask);
+        u64 *rval = const_cast<u64 *>(eval), *dg = const_cast<u64 *>(diag);
+        const int E = hdr[img].npairs;
+        s_blen[tid] = 0;
+        for (int i = tid; i < nb * 64; i += 1024) dg[i] = 0ull;
+        __syncthreads();
+        for (int e = tid; e < E; e += 1024) atomicAdd(&s_blen[ekey[e] >> 22], 1);
+        __syncthreads();
+        {
+            const int v = s_blen[tid];
+            int incl = v;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
+            if (lane == 63) s_wsum[wave] = incl;
+            __syncthreads();
+            int base = 0;
+            for (int k = 0; k < wave; ++k) base += s_wsum[k];
+            s_boff[tid] = base + incl - v;
+            s_cur[tid] = base + incl - v;
+        }
+        __syncthreads();
+        for (int e = tid; e < E; e += 1024) {
+            const u32 key = ekey[e], lo = key >> 16, hi = key & 0xffffu;
+            const int at = atomicAdd(&s_cur[lo >> 6], 1);
+            rkey[at] = ((lo & 63u) << 16) | (hi >> 6);
+            rval[at] = 1ull << (hi & 63u);
+            if ((hi >> 6) == (lo >> 6)) atomicOr((unsigned long long *)&dg[lo], 1ull << (hi & 63u));
+        }
+        __syncthreads();                                      // the runs were written by this workgroup: visible to it from here on
+        ekey = rkey;
+    } else {
+        for (int w = tid; w < nb; w += 1024) { const int o = boff[w]; s_boff[w] = o; s_blen[w] = boff[w + 1] - o; }
+    }
     if (tid < 2) s_new[tid] = 0;
     __syncthreads();
 
@@ -839,11 +954,11 @@ __global__ __launch_bounds__(1024) void k_nms_reduce_csr(const u64 *__restrict__
     for (int j = 0; j < CSR_AHEAD; ++j) { hkey[j] = 0; hval[j] = 0; hdiag[j] = 0; hord[j] = 0; hlen[j] = 0; }
     auto fetch = [&](int j, int b) {
         if (b >= nb) return;
-        const int o = s_boff[b], len = s_boff[b + 1] - o;
+        const int o = s_boff[b], len = s_blen[b];
         hlen[j] = len;
         hkey[j] = (tid < len) ? ekey[o + tid] : 0u;
         hval[j] = (tid < len) ? eval[o + tid] : 0ull;
-        if (wave == 0) { hdiag[j] = mask[((int64_t)b * 64 + lane) * W + b]; hord[j] = order[b * 64 + lane]; }
+        if (wave == 0) { hdiag[j] = SEG ? diag[b * 64 + lane] : mask[((int64_t)b * 64 + lane) * W + b]; hord[j] = order[b * 64 + lane]; }
     };
     auto publish = [&](int j, int slot) {
         s_key[slot][tid] = hkey[j];
@@ -888,13 +1003,15 @@ __global__ __launch_bounds__(1024) void k_nms_reduce_csr(const u64 *__restrict__
             const u64 others = kept & ~(1ull << rl);
             if (tid < len) {
                 const u32 k = s_key[slot][tid];
-                if ((others >> (k >> 16)) & 1ull) atomicOr((unsigned long long *)&remv[k & 0xffffu], (unsigned long long)s_val[slot][tid]);
+                if (((others >> (k >> 16)) & 1ull) && (!SEG || (int)(k & 0xffffu) != ib))
+                    atomicOr((unsigned long long *)&remv[k & 0xffffu], (unsigned long long)s_val[slot][tid]);
             }
             if (len > CSR_LDS_ENTRIES) {                    // a long run: its tail straight from memory
                 const int o = s_boff[ib];
                 for (int e = CSR_LDS_ENTRIES + tid; e < len; e += 1024) {
                     const u32 k = ekey[o + e];
-                    if ((others >> (k >> 16)) & 1ull) atomicOr((unsigned long long *)&remv[k & 0xffffu], (unsigned long long)eval[o + e]);
+                    if (((others >> (k >> 16)) & 1ull) && (!SEG || (int)(k & 0xffffu) != ib))
+                        atomicOr((unsigned long long *)&remv[k & 0xffffu], (unsigned long long)eval[o + e]);
                 }
             }
         }
@@ -904,7 +1021,7 @@ __global__ __launch_bounds__(1024) void k_nms_reduce_csr(const u64 *__restrict__
             int fresh = 0;
             if (tid < len) {
                 const u32 k = s_key[slot][tid];
-                if ((int)(k >> 16) == rl) {
+                if ((int)(k >> 16) == rl && (!SEG || (int)(k & 0xffffu) != ib)) {
                     const u64 v = s_val[slot][tid];
                     const u64 old = atomicOr((unsigned long long *)&remv[k & 0xffffu], (unsigned long long)v);
                     fresh = __builtin_popcountll(v & ~old);
@@ -914,7 +1031,7 @@ __global__ __launch_bounds__(1024) void k_nms_reduce_csr(const u64 *__restrict__
                 const int o = s_boff[ib];
                 for (int e = CSR_LDS_ENTRIES + tid; e < len; e += 1024) {
                     const u32 k = ekey[o + e];
-                    if ((int)(k >> 16) == rl) {
+                    if ((int)(k >> 16) == rl && (!SEG || (int)(k & 0xffffu) != ib)) {
                         const u64 v = eval[o + e];
                         const u64 old = atomicOr((unsigned long long *)&remv[k & 0xffffu], (unsigned long long)v);
                         fresh += __builtin_popcountll(v & ~old);
@@ -946,12 +1063,409 @@ __global__ __launch_bounds__(1024) void k_nms_reduce_csr(const u64 *__restrict__
     if (tid == 0) keep_count[img] = total;
 }
 
+// ---------------------------------------------------------------- pruned path (64 < W <= 1024): no N x N mask
+// A pair whose boxes do not overlap has IoU 0 < thr (thr > 0, finite areas), so only overlapping pairs can suppress, and a set
+// of small boxes has few of them.  The score-sorted boxes are counting-sorted by the x-bucket of their left edge (XB_G buckets
+// over [min x1, max x1]: the bucket function is monotone, ties inside a bucket in any order).  In that order box p can only
+// overlap a later box q if x1_q < x2_p, i.e. q lies before the end of bucket(x2_p): the pair search is the mask kernel's
+// 64-row x 64-column pass over a BAND of column tiles instead of the whole triangle (config 5's sparse set: 31 tiles per
+// row tile instead of 513 on average).  Every suppressing pair is found exactly once (position order is a total order) and
+// emitted as a compact entry (lower rank's row in its 64-row block << 16 | word of the higher rank, one bit) into the lower
+// rank's block segment -- the form k_nms_reduce_csr consumes -- so the 512 MiB mask is neither written nor read.
+//   k_nms_xbucket : one workgroup per image: min/max of x1, non-finite boxes (-> dense path), histogram, scan, each box's
+//                   position; the exact number of candidate pairs decides between this path and the dense mask (hdr.mode);
+//   k_nms_xb_scatter: boxes into x-bucket order (bbox = corners, bar = {area, rank});
+//   k_nms_band    : the pair search;
+//   k_nms_resolve_fp: the greedy keep list as a fixed point instead of a serial chain (below).
+#define XB_G 4096
+#define BAND_STAGE 256
+__device__ __forceinline__ int xb_bucket(float x, float xmin, float scale)
+{
+    return (int)fminf(fmaxf((x - xmin) * scale, 0.0f), (float)(XB_G - 1));      // monotone in x; a NaN product (inf * 0) -> 0
+}
+
+#define XB_STRIDE 4352            // ints per array in the bucket workspace (XB_G + 1, padded)
+// the bucket scale of an image from the range k_nms_gather found (every thread recomputes it: two loads)
+__device__ __forceinline__ void xb_range(const NmsHdr *h, float *xmin, float *scale)
+{
+    const float mn = xb_unord(h->xmin_i), mx = xb_unord(h->xmax_i);
+    const float range = mx - mn;
+    float sc = (float)XB_G / range;
+    if (!(range > 0.0f) || !(sc < INFINITY)) sc = 0.0f;          // everything in bucket 0: the candidate count then says "dense"
+    *xmin = mn; *scale = sc;
+}
+
+// histogram of the left edges' buckets and of the right edges' (global atomics: 4096 counters in L2)
+__global__ __launch_bounds__(256) void k_nms_xb_hist(const float *__restrict__ sx1, const float *__restrict__ sx2,
+                                                     const int32_t *__restrict__ counts, int64_t nmax, int64_t Np,
+                                                     const NmsHdr *__restrict__ hdr, int32_t *__restrict__ xb)
+{
+    const int img = blockIdx.y;
+    const NmsHdr *h = hdr + img;
+    const int n = counts ? counts[img] : (int)nmax;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || h->bad) return;
+    float mn, sc;
+    xb_range(h, &mn, &sc);
+    const float a = sx1[(int64_t)img * Np + i], b = sx2[(int64_t)img * Np + i];
+    int32_t *x = xb + (int64_t)img * 4 * XB_STRIDE;
+    atomicAdd(&x[xb_bucket(a, mn, sc)], 1);
+    atomicAdd(&x[XB_STRIDE + xb_bucket(fmaxf(a, b), mn, sc)], 1);   // an inverted box overlaps nothing; its range is empty
+}
+
+// one workgroup per image: bucket starts, the EXACT number of candidate pairs (for each box the boxes whose left edge
+// lies in the buckets its x range touches: sum_b hist2[b] * start[b + 1] - sum_b hist1[b] * start[b]) and with it the
+// decision between this path and the dense mask
+__global__ __launch_bounds__(1024) void k_nms_xb_scan(const int32_t *__restrict__ counts, int64_t nmax, int force,
+                                                      NmsHdr *__restrict__ hdr, int32_t *__restrict__ xb)
+{
+    __shared__ int s_part[16];
+    __shared__ unsigned long long s_cand;
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = counts ? counts[img] : (int)nmax;
+    NmsHdr *h = hdr + img;
+    int32_t *x = xb + (int64_t)img * 4 * XB_STRIDE;
+    if (tid == 0) s_cand = 0ull;
+    const int c0 = x[4 * tid], c1 = x[4 * tid + 1], c2 = x[4 * tid + 2], c3 = x[4 * tid + 3];
+    const int mine = c0 + c1 + c2 + c3;
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
+    if (lane == 63) s_part[wave] = incl;
+    __syncthreads();
+    int base = 0;
+    for (int k = 0; k < wave; ++k) base += s_part[k];
+    const int e0 = base + incl - mine, e1 = e0 + c0, e2 = e1 + c1, e3 = e2 + c2, e4 = e3 + c3;
+    int32_t *st = x + 2 * XB_STRIDE, *cur = x + 3 * XB_STRIDE;
+    st[4 * tid] = e0; st[4 * tid + 1] = e1; st[4 * tid + 2] = e2; st[4 * tid + 3] = e3;
+    cur[4 * tid] = e0; cur[4 * tid + 1] = e1; cur[4 * tid + 2] = e2; cur[4 * tid + 3] = e3;
+    if (tid == 1023) st[XB_G] = e4;
+    const int32_t *h2 = x + XB_STRIDE;
+    long long cand = (long long)h2[4 * tid] * e1 + (long long)h2[4 * tid + 1] * e2 + (long long)h2[4 * tid + 2] * e3 + (long long)h2[4 * tid + 3] * e4
+                     - ((long long)c0 * e0 + (long long)c1 * e1 + (long long)c2 * e2 + (long long)c3 * e3);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) cand += __shfl_xor(cand, d, 64);
+    if (lane == 0) atomicAdd(&s_cand, (unsigned long long)cand);
+    __syncthreads();
+    if (tid == 0) {
+        float mn, sc;
+        xb_range(h, &mn, &sc);
+        // the band kernel tests about 1.8 x cand pairs (a row tile runs to the end of its widest box), the dense mask n^2 / 2
+        const bool prune = !h->bad && n > 64 && force != 0 &&
+                           (force == 2 || s_cand * 8ull <= (unsigned long long)n * (unsigned long long)n);
+        h->xmin = mn; h->scale = sc; h->mode = prune ? 0 : 1;
+    }
+}
+
+// boxes into x-bucket order: bbox = corners, bar = {area, rank}; inside a bucket in the order the cursor hands out
+__global__ __launch_bounds__(256) void k_nms_xb_place(const float *__restrict__ sx1, const float *__restrict__ sy1,
+                                                      const float *__restrict__ sx2, const float *__restrict__ sy2,
+                                                      const float *__restrict__ sarea, const int32_t *__restrict__ counts,
+                                                      int64_t nmax, const NmsHdr *__restrict__ hdr, int64_t Np,
+                                                      int32_t *__restrict__ xb, float4 *__restrict__ bbox, float2 *__restrict__ bar)
+{
+    const int img = blockIdx.y;
+    const NmsHdr *h = hdr + img;
+    if (h->mode != 0) return;
+    const int n = counts ? counts[img] : (int)nmax;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= Np) return;
+    const int64_t o = (int64_t)img * Np;
+    const float a = sx1[o + i];
+    int64_t p = i;                                               // the zero boxes of the padding stay behind the real ones
+    if (i < n) p = atomicAdd(&xb[(int64_t)img * 4 * XB_STRIDE + 3 * XB_STRIDE + xb_bucket(a, h->xmin, h->scale)], 1);
+    bbox[o + p] = make_float4(a, sy1[o + i], sx2[o + i], sy2[o + i]);
+    bar[o + p] = make_float2(sarea[o + i], __int_as_float((int)i));
+}
+
+__global__ void k_nms_force_dense(NmsHdr *__restrict__ hdr, int batch)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < batch) { hdr[i].mode = 1; hdr[i].fpdone = 0; }
+}
+
+// grid: x = part of the band (waves of all parts stride the column tiles together), y = row tile (64 boxes in x-bucket
+// order), z = image.  The 64-row pass is k_nms_mask's (same division-free test, same exact redo); what differs is where
+// the bits go.
+template <bool TIE_EVEN>
+__global__ __launch_bounds__(256, 4) void k_nms_band(const float4 *__restrict__ bbox, const float2 *__restrict__ bar,
+                                                     const int32_t *__restrict__ start, NmsHdr *__restrict__ hdr,
+                                                     const int32_t *__restrict__ counts, int64_t nmax, int64_t Np,
+                                                     int64_t ecap, float thr, float thr_below, double mid, u32 *__restrict__ elist)
+{
+    __shared__ float4 rbox[64];
+    __shared__ float rarea[64];
+    __shared__ int rrank[64];
+    __shared__ int s_jend;
+    __shared__ u32 s_stage[4][BAND_STAGE];                         // a wave's pairs wait here: one bump of the list cursor per flush
+    const int img = blockIdx.z;
+    NmsHdr *h = hdr + img;
+    if (h->mode != 0) return;
+    const int n = counts ? counts[img] : (int)nmax;
+    const int t = blockIdx.y;
+    if (t * 64 >= n) return;
+    const int64_t o = (int64_t)img * Np;
+    elist += (int64_t)img * (ecap + CSR_SLACK);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 64) {
+        const float4 b = bbox[o + t * 64 + tid];
+        const float2 ar = bar[o + t * 64 + tid];
+        rbox[tid] = b; rarea[tid] = ar.x; rrank[tid] = __float_as_int(ar.y);
+        float x2 = (t * 64 + tid < n) ? b.z : -INFINITY;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) x2 = fmaxf(x2, __shfl_xor(x2, d, 64));
+        if (tid == 0) {
+            const int be = xb_bucket(x2, h->xmin, h->scale);
+            const int jend = (start[(int64_t)img * 4 * XB_STRIDE + 2 * XB_STRIDE + be + 1] - 1) >> 6;   // last column tile that can hold a partner
+            s_jend = jend > t ? jend : t;
+        }
+    }
+    __syncthreads();
+    const int jend = s_jend;
+    const float2 *cbar = bar + o;
+    u32 *stage = s_stage[wave];
+    int staged = 0;                                                // wave-uniform
+    auto flush = [&]() {
+        if (staged == 0) return;
+        int base = 0;
+        if (lane == 0) {
+            base = atomicAdd(&h->npairs, staged);
+            if ((int64_t)base + staged > ecap) *(volatile int32_t *)&h->mode = 1;      // list full: the dense path redoes this image
+        }
+        base = __shfl(base, 0, 64);
+        for (int i = lane; i < staged; i += 64)
+            if (base + i < ecap) elist[base + i] = stage[i];
+        staged = 0;
+    };
+#pragma unroll 1
+    for (int j = t + (int)blockIdx.x * 4 + wave; j <= jend; j += 4 * (int)gridDim.x) {       // wave-uniform
+        asm volatile("" ::: "memory");
+        const float4 cb = bbox[o + (int64_t)j * 64 + lane];
+        const float ca = cbar[(int64_t)j * 64 + lane].x;
+        const float cx1 = cb.x, cy1 = cb.y, cx2 = cb.z, cy2 = cb.w;
+        u32 wlo = 0, whi = 0;
+        u64 ambany = 0;
+#pragma unroll
+        for (int r = 0; r < 64; ++r) {
+            const float4 p = rbox[r];
+            const float ix = vmax(vmin(p.z, cx2) - vmax(p.x, cx1), 0.0f);
+            const float iy = vmax(vmin(p.w, cy2) - vmax(p.y, cy1), 0.0f);
+            const float inter = ix * iy;
+            const float den = ((rarea[r] + ca) - inter) + 1e-7f;
+            const float e1 = __builtin_fmaf(-thr, den, inter), e2 = __builtin_fmaf(-thr_below, den, inter);
+            const u64 bal = __ballot(!(e1 < 0.0f));
+            ambany |= __ballot(e2 > 0.0f) & ~bal;
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(wlo) : "s"((u32)bal), "n"(r));
+            asm("v_writelane_b32 %0, %1, %2" : "+v"(whi) : "s"((u32)(bal >> 32)), "n"(r));
+        }
+        u64 myword = ((u64)whi << 32) | wlo;                       // lane = row, bit = column of this tile
+        if (ambany) {                                             // rare: a quotient within one ulp of thr somewhere
+            u64 w2 = 0;
+#pragma unroll 2
+            for (int r = 0; r < 64; ++r) {
+                const float4 p = rbox[r];
+                const float ix = fmaxf(fminf(p.z, cx2) - fmaxf(p.x, cx1), 0.0f);
+                const float iy = fmaxf(fminf(p.w, cy2) - fmaxf(p.y, cy1), 0.0f);
+                const float inter = ix * iy;
+                const float den = ((rarea[r] + ca) - inter) + 1e-7f;
+                const u64 bal = __ballot(nms_suppressed<TIE_EVEN>(inter, den, mid));
+                if (lane == r) w2 = bal;
+            }
+            myword = w2;
+        }
+        if (j == t) myword &= ~((2ull << lane) - 1ull);            // later positions only: every pair once
+        const int cnt = __builtin_popcountll(myword);
+        if (__ballot(cnt != 0)) {                                  // wave-uniform: one cursor bump for the wave's pairs
+            int incl = cnt;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
+            const int total = __shfl(incl, 63, 64);
+            const bool direct = total > BAND_STAGE;                // a tile of near-duplicates: straight to the list
+            if (!direct && staged + total > BAND_STAGE) flush();
+            int base = 0;
+            if (direct) {
+                if (lane == 0) {
+                    base = atomicAdd(&h->npairs, total);
+                    if ((int64_t)base + total > ecap) *(volatile int32_t *)&h->mode = 1;
+                }
+                base = __shfl(base, 0, 64);
+            }
+            int at = (direct ? base : staged) + incl - cnt;
+            if (myword) {
+                const int rr = rrank[lane];
+                while (myword) {
+                    const int c = __builtin_ctzll(myword);
+                    myword &= myword - 1;
+                    const int cr = __float_as_int(cbar[(int64_t)j * 64 + c].y);
+                    const u32 lo = (u32)(rr < cr ? rr : cr), hi = (u32)(rr < cr ? cr : rr);
+                    const u32 key = (lo << 16) | hi;               // ranks < 65536 (W <= 1024)
+                    if (direct) { if (at < ecap) elist[at] = key; }
+                    else stage[at] = key;
+                    ++at;
+                }
+            }
+            if (!direct) staged += total;
+        }
+    }
+    flush();
+}
+
+// The keep list as a FIXED POINT instead of a chain over 64-row blocks.  A box is kept iff no kept box of higher rank
+// suppresses it; with the suppressing pairs as a list of entries (source row, target word, bits) that unfolds in rounds:
+//   an entry whose source is KEPT marks its targets REMOVED and dies; one whose source is REMOVED dies; one whose source is
+//   still undecided blocks its targets for this round; after the pass every undecided box that nothing blocks is KEPT.
+// The highest-ranked undecided box is decided in every round, so it ends; with scores independent of geometry the number of
+// rounds grows like log^2 n (parallel greedy MIS), about ten for config 5.  One 1024-thread workgroup per image, the four bit
+// sets in LDS, the live entries in a work list that shrinks every round.  After `max_rounds` (or a full work list) it gives
+// up and k_nms_reduce_csr<SEG> walks the segments serially instead (a chain of n boxes each suppressing the next would
+// need n rounds).  R2 = targets marked by at least two kept sources: the reference's `numel()>1` quirk (yolo.py:196) drops
+// the last kept box iff every lower-ranked box was already removed by OTHER kept boxes, i.e. iff no target of its own
+// entries has only it as kept suppressor.
+__global__ __launch_bounds__(1024) void k_nms_resolve_fp(NmsHdr *__restrict__ hdr, const int32_t *__restrict__ counts, int64_t nmax,
+                                                         int64_t Np, int64_t W, int64_t ecap, const u32 *__restrict__ elist,
+                                                         const int32_t *__restrict__ order, u64 *__restrict__ maskws, int max_rounds,
+                                                         int quirk, int64_t *__restrict__ keep, int32_t *__restrict__ keep_count)
+{
+    __shared__ u64 K[1024], R[1024], R2[1024], Bk[1024];
+    __shared__ int s_off[1024];
+    __shared__ int s_last, s_part[16];
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    NmsHdr *h = hdr + img;
+    if (h->mode != 0) return;
+    const int n = counts ? counts[img] : (int)nmax;
+    const int nb = (n + 63) >> 6;
+    const int E = h->npairs;                                     // <= ecap (mode would be 1 otherwise)
+    elist += (int64_t)img * (ecap + CSR_SLACK);
+    order += (int64_t)img * Np;
+    keep += (int64_t)img * nmax;
+    u32 *wl[1];                                                  // the work list (ecap entries) lives in this image's unused dense mask
+    wl[0] = (u32 *)(maskws + (int64_t)img * Np * W);
+    const int64_t vb = (int64_t)tid * 64;
+    const u64 valid = (vb >= n) ? 0ull : ((n - vb >= 64) ? ~0ull : ((1ull << (n - vb)) - 1ull));   // of word `tid`
+    K[tid] = 0ull; R[tid] = 0ull; R2[tid] = 0ull; Bk[tid] = 0ull;
+    if (tid == 0) s_last = -1;
+    __syncthreads();
+    // round 0: boxes nothing suppresses are kept
+    for (int e0 = 0; e0 < E; e0 += 8 * 1024) {
+        u32 k[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int e = e0 + u * 1024 + tid; k[u] = e < E ? elist[e] : 0xffffffffu; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            if (k[u] != 0xffffffffu) atomicOr((unsigned long long *)&Bk[(k[u] & 0xffffu) >> 6], 1ull << (k[u] & 63u));   // lo < hi: never all ones
+    }
+    __syncthreads();
+    K[tid] = valid & ~Bk[tid];
+    Bk[tid] = 0ull;
+    __syncthreads();
+    // Thread t owns the 16-byte chunks t, t + 1024, t + 2048, ... of the pair list (four entries each); the entries that
+    // stay live it writes back to the same chunks of the work list, in order (in place from the second round on: the write
+    // index never passes the read index), so no cursor, no atomics on memory, coalesced accesses and 32 entries in flight
+    // per thread.  One entry: its source is KEPT -> mark the target REMOVED (and R2 if it already was), dead; REMOVED ->
+    // dead; undecided -> block the target for this round, live.  For the quirk every thread remembers the targets of the
+    // highest-ranked kept source it applied (the last kept box, if it has entries at all, is that for some thread).
+    const u32 *src_list = elist;
+    u32 *wlist = wl[0];
+    int mycnt = 0;
+    for (int64_t c = tid; c * 4 < E; c += 1024) mycnt += (E - c * 4 >= 4) ? 4 : (int)(E - c * 4);
+    int rounds = 0, bsrc = -1, bn = 0;
+    u64 bpack = 0;
+    bool bail = false;
+    for (;;) {
+        if (!__syncthreads_or(mycnt > 0)) break;                 // no live entry anywhere: every box is decided
+        if (rounds >= max_rounds) { bail = true; break; }
+        int out = 0;
+        const int nch = (mycnt + 3) >> 2;
+        for (int c0 = 0; c0 < nch; c0 += 8) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[u] = (c0 + u < nch) ? *(const uint4 *)(src_list + 4 * (tid + 1024 * (c0 + u))) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const u32 key = q == 0 ? v[u].x : (q == 1 ? v[u].y : (q == 2 ? v[u].z : v[u].w));
+                    if ((c0 + u) * 4 + q >= mycnt) continue;
+                    const u32 src = key >> 16, dst = key & 0xffffu;
+                    const u64 sb = 1ull << (src & 63), db = 1ull << (dst & 63);
+                    if (K[src >> 6] & sb) {
+                        const u64 old = atomicOr((unsigned long long *)&R[dst >> 6], (unsigned long long)db);
+                        if (old & db) atomicOr((unsigned long long *)&R2[dst >> 6], (unsigned long long)db);
+                        if ((int)src > bsrc) { bsrc = (int)src; bn = 0; }
+                        if ((int)src == bsrc) { bpack = (bpack << 16) | dst; ++bn; }
+                    } else if (!(R[src >> 6] & sb)) {
+                        atomicOr((unsigned long long *)&Bk[dst >> 6], (unsigned long long)db);
+                        wlist[4 * (tid + 1024 * (out >> 2)) + (out & 3)] = key;
+                        ++out;
+                    }
+                }
+            }
+        }
+        mycnt = out;
+        src_list = wlist;
+        __syncthreads();
+        if (tid < nb) { K[tid] |= valid & ~(K[tid] | R[tid] | Bk[tid]); Bk[tid] = 0ull; }      // what nothing blocks is kept
+        ++rounds;
+    }
+    if (bail) {                                                  // uniform: k_nms_reduce_csr<SEG> does this image from scratch
+        if (tid == 0) { h->fpdone = 0; h->rounds = rounds; }
+        return;
+    }
+    // ---- K is final: count, quirk, keep list in rank order
+    const u64 kw = K[tid];
+    const int mine = __builtin_popcountll(kw);
+    int incl = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
+    if (lane == 63) s_part[wave] = incl;
+    if (kw) atomicMax(&s_last, tid * 64 + 63 - __builtin_clzll(kw));
+    __syncthreads();
+    int base = 0, total = 0;
+    for (int k = 0; k < 16; ++k) { if (k < wave) base += s_part[k]; total += s_part[k]; }
+    s_off[tid] = base + incl - mine;                             // keep-list offset of word `tid`
+    const int km = s_last;
+    int drop = 0;
+    if (quirk && total > 0) {                                    // uniform
+        // the last kept box's own targets: from the threads that applied its entries; a thread that met more than four of
+        // them (a 64-bit pack) sends everybody through the whole list instead
+        const bool own = bsrc == km;
+        if (__syncthreads_or(own && bn > 4)) {
+            for (int e = tid; e < E; e += 1024) {
+                const u32 key = elist[e];
+                if ((int)(key >> 16) == km) atomicOr((unsigned long long *)&Bk[(key & 0xffffu) >> 6], 1ull << (key & 63u));
+            }
+        } else if (own) {
+            for (int q = 0; q < bn; ++q) {
+                const u32 dst = (u32)(bpack >> (16 * q)) & 0xffffu;
+                atomicOr((unsigned long long *)&Bk[dst >> 6], 1ull << (dst & 63u));
+            }
+        }
+        __syncthreads();
+        drop = !__syncthreads_or((Bk[tid] & ~R2[tid]) != 0ull);  // none of them was left to it alone: nothing survived k1..k(m-1)
+    } else {
+        __syncthreads();
+    }
+    for (int w = wave; w < nb; w += 16) {
+        u64 k = K[w];
+        if (drop && w == (km >> 6)) k &= ~(1ull << (km & 63));
+        if ((k >> lane) & 1ull) keep[s_off[w] + __builtin_popcountll(k & ((1ull << lane) - 1ull))] = (int64_t)order[w * 64 + lane];
+    }
+    if (tid == 0) { keep_count[img] = total - drop; h->fpdone = 1; h->rounds = rounds; }
+}
+
 // ---------------------------------------------------------------- host
 extern "C" size_t dg_nms_workspace_bytes(int64_t batch, int64_t nmax)
 {
     if (batch <= 0 || nmax < 0) return 0;
     return nms_layout(batch, nmax, nullptr).total;
 }
+
+// DG_NMS_PRUNE: 0 = never take the pruned path, 1 (default) = where the candidate count says so, 2 = wherever it applies
+// (64 < W <= 1024, finite boxes, 2^-20 <= thr < inf), whatever the candidate count (tests).  DG_NMS_FP_ROUNDS: rounds after
+// which k_nms_resolve_fp hands over to the serial chain (default 128; 1 in tests sends every image there).
+static int nms_prune_mode() { const char *e = getenv("DG_NMS_PRUNE"); return e ? atoi(e) : 1; }
+static int nms_fp_rounds() { const char *e = getenv("DG_NMS_FP_ROUNDS"); return e ? atoi(e) : 128; }
 
 static int nms_check(const char *fn, int64_t batch, int64_t nmax, void *ws, size_t ws_bytes, NmsWs *out)
 {
@@ -983,6 +1497,7 @@ extern "C" int dg_nms_phase_sort(const float *boxes, const float *scores, const 
     DG_REQUIRE(boxes && scores, "nms_sort: null pointer");
     DG_REQUIRE((((uintptr_t)boxes) & 15) == 0, "nms_sort: boxes must be 16-byte aligned");
     hipStream_t st = (hipStream_t)s;
+    const bool prune = w.pruned && nms_prune_mode() != 0;
     switch (w.Np2) {
     case 64: launch_sort_small<64>(w, boxes, scores, counts, batch, nmax, st); break;
     case 128: launch_sort_small<128>(w, boxes, scores, counts, batch, nmax, st); break;
@@ -993,7 +1508,8 @@ extern "C" int dg_nms_phase_sort(const float *boxes, const float *scores, const 
     case 4096: launch_sort_small<4096>(w, boxes, scores, counts, batch, nmax, st); break;
     default: {
         const int64_t Np2 = w.Np2;
-        hipLaunchKernelGGL(k_nms_make_keys, dim3((unsigned)(Np2 / 256), (unsigned)batch), dim3(256), 0, st, scores, counts, nmax, Np2, w.keys);
+        hipLaunchKernelGGL(k_nms_make_keys, dim3((unsigned)(Np2 / 256), (unsigned)batch), dim3(256), 0, st, scores, counts, nmax, Np2, w.keys,
+                           prune ? w.hdr : (NmsHdr *)nullptr, w.start);
         dim3 gl((unsigned)(Np2 / SORT_CHUNK), (unsigned)batch), gg((unsigned)(Np2 / 2 / 256), (unsigned)batch);
         hipLaunchKernelGGL(k_bitonic_lds, gl, dim3(1024), 0, st, w.keys, Np2, (int64_t)2, (int64_t)SORT_CHUNK, 1);
         for (int64_t k = 2 * SORT_CHUNK; k <= Np2; k <<= 1) {
@@ -1002,10 +1518,18 @@ extern "C" int dg_nms_phase_sort(const float *boxes, const float *scores, const 
             hipLaunchKernelGGL(k_bitonic_lds, gl, dim3(1024), 0, st, w.keys, Np2, k, k, SORT_CHUNK / 2);
         }
         hipLaunchKernelGGL(k_nms_gather, dim3((unsigned)dg_cdiv(w.Np, 256), (unsigned)batch), dim3(256), 0, st, (const float4 *)boxes,
-                           w.keys, counts, nmax, w.Np, Np2, w.x1, w.y1, w.x2, w.y2, w.area, w.order);
+                           w.keys, counts, nmax, w.Np, Np2, w.x1, w.y1, w.x2, w.y2, w.area, w.order, prune ? w.hdr : (NmsHdr *)nullptr);
     }
     }
     DG_CHECK_LAUNCH("nms sort");
+    if (prune) {
+        hipLaunchKernelGGL(k_nms_xb_hist, dim3((unsigned)dg_cdiv(w.Np, 256), (unsigned)batch), dim3(256), 0, st, w.x1, w.x2, counts, nmax, w.Np,
+                           w.hdr, w.start);
+        hipLaunchKernelGGL(k_nms_xb_scan, dim3((unsigned)batch), dim3(1024), 0, st, counts, nmax, nms_prune_mode(), w.hdr, w.start);
+        hipLaunchKernelGGL(k_nms_xb_place, dim3((unsigned)dg_cdiv(w.Np, 256), (unsigned)batch), dim3(256), 0, st, w.x1, w.y1, w.x2, w.y2,
+                           w.area, counts, nmax, w.hdr, w.Np, w.start, w.bbox, w.bar);
+        DG_CHECK_LAUNCH("k_nms_xbucket");
+    }
     return DG_OK;
 }
 
@@ -1023,10 +1547,28 @@ extern "C" int dg_nms_phase_mask(const int32_t *counts, int64_t batch, int64_t n
     // 32-word tiles; small launches (one image of a few thousand boxes) take 8-word tiles so that more than a handful of
     // workgroups exist: 2000 boxes = 32 row blocks x 1 tile would keep 32 of 256 CUs busy
     const bool small = dg_cdiv(w.W, 32) * w.W * batch < 512;
+    const NmsHdr *hdr = nullptr;
+    if (w.pruned && nms_prune_mode() != 0) {
+        // the pruned pair search for the images k_nms_xbucket chose (hdr.mode == 0); the dense mask below runs for the others
+        hdr = w.hdr;
+        if (!fast_ok) {
+            hipLaunchKernelGGL(k_nms_force_dense, dim3((unsigned)dg_cdiv(batch, 256)), dim3(256), 0, (hipStream_t)s, w.hdr, (int)batch);
+        } else {
+            const unsigned parts = (unsigned)(w.W >= 1024 ? 2 : (w.W >= 512 ? 4 : 8));
+            const dim3 g(parts, (unsigned)w.W, (unsigned)batch);
+            if (tie_even)
+                hipLaunchKernelGGL((k_nms_band<true>), g, dim3(256), 0, (hipStream_t)s, w.bbox, w.bar, w.start, w.hdr, counts, nmax, w.Np,
+                                   w.ecap, threshold, below, mid, w.ekey);
+            else
+                hipLaunchKernelGGL((k_nms_band<false>), g, dim3(256), 0, (hipStream_t)s, w.bbox, w.bar, w.start, w.hdr, counts, nmax, w.Np,
+                                   w.ecap, threshold, below, mid, w.ekey);
+        }
+        DG_CHECK_LAUNCH("k_nms_band");
+    }
 #define MASK_LAUNCH(TE, MTW)                                                                                                     \
     hipLaunchKernelGGL((k_nms_mask<TE, MTW>), dim3((unsigned)dg_cdiv(w.W, MTW), (unsigned)w.W, (unsigned)batch), dim3(256), 0,   \
                        (hipStream_t)s, w.x1, w.y1, w.x2, w.y2, w.area, counts, nmax, w.Np, w.W, w.SW, threshold, below, mid,     \
-                       fast_ok, w.mask, w.rsum)
+                       fast_ok, w.mask, w.rsum, hdr)
     if (tie_even) { if (small) MASK_LAUNCH(true, 8); else MASK_LAUNCH(true, 32); }
     else { if (small) MASK_LAUNCH(false, 8); else MASK_LAUNCH(false, 32); }
 #undef MASK_LAUNCH
@@ -1046,6 +1588,16 @@ extern "C" int dg_nms_phase_reduce(const int32_t *counts, int64_t batch, int64_t
     DG_REQUIRE(keep, "nms_reduce: null keep");
 #define RED(T, WPT) hipLaunchKernelGGL((k_nms_reduce<T, WPT>), dim3((unsigned)batch), dim3(T), 0, st, w.mask, w.order, counts, \
                                        nmax, w.Np, w.W, quirk_drop_last, keep, keep_count)
+    const NmsHdr *hdr = nullptr;
+    if (w.pruned && nms_prune_mode() != 0) {
+        hdr = w.hdr;
+        hipLaunchKernelGGL(k_nms_resolve_fp, dim3((unsigned)batch), dim3(1024), 0, st, w.hdr, counts, nmax, w.Np, w.W, w.ecap, w.ekey,
+                           w.order, w.mask, nms_fp_rounds(), quirk_drop_last, keep, keep_count);
+        hipLaunchKernelGGL(k_nms_reduce_csr<true>, dim3((unsigned)batch), dim3(1024), 0, st, w.mask, w.order, counts, nmax, w.Np,
+                           w.W, w.ecap, (const int32_t *)nullptr, (const int32_t *)nullptr, w.ekey, w.eval, quirk_drop_last, keep, keep_count,
+                           w.hdr, w.diag);
+        DG_CHECK_LAUNCH("k_nms_resolve_fp");
+    }
     if (w.W < NMS_CSR_MIN_W) RED(64, 1);
     else if (w.W <= 1024) {
         // compact the mask, then the LDS-fed reduce; an image whose entries do not fit falls to the summary-driven kernel
@@ -1057,21 +1609,21 @@ extern "C" int dg_nms_phase_reduce(const int32_t *counts, int64_t batch, int64_t
                                ecap_fit, w.ecap, w.boff, w.cflag, w.ekey, w.eval);
         } else {
             hipLaunchKernelGGL(k_nms_csr_count, dim3((unsigned)(w.Np / 256 + (w.Np % 256 != 0)), (unsigned)batch), dim3(256), 0, st, w.rsum,
-                               counts, nmax, w.Np, w.W, w.SW, w.bcnt);
+                               counts, nmax, w.Np, w.W, w.SW, w.bcnt, hdr);
             hipLaunchKernelGGL(k_nms_csr_scan, dim3((unsigned)batch), dim3(1024), 0, st, w.bcnt, counts, nmax, w.W, ecap_fit, w.boff, w.cursor,
-                               w.cflag);
+                               w.cflag, hdr);
             if ((w.SW & (w.SW - 1)) == 0 && w.SW <= 64) {
                 int sh = 0;
                 while ((1ll << sh) < w.SW) ++sh;
                 hipLaunchKernelGGL(k_nms_csr_fill_wave, dim3((unsigned)dg_cdiv(w.Np * w.SW, 256), (unsigned)batch), dim3(256), 0, st, w.mask,
-                                   w.rsum, counts, nmax, w.Np, w.W, w.SW, sh, w.ecap, w.cflag, w.cursor, w.ekey, w.eval);
+                                   w.rsum, counts, nmax, w.Np, w.W, w.SW, sh, w.ecap, w.cflag, w.cursor, w.ekey, w.eval, hdr);
             } else {
                 hipLaunchKernelGGL(k_nms_csr_fill, dim3((unsigned)dg_cdiv(w.Np * w.SW, 256), (unsigned)batch), dim3(256), 0, st, w.mask, w.rsum,
-                                   counts, nmax, w.Np, w.W, w.SW, w.ecap, w.cflag, w.cursor, w.ekey, w.eval);
+                                   counts, nmax, w.Np, w.W, w.SW, w.ecap, w.cflag, w.cursor, w.ekey, w.eval, hdr);
             }
         }
-        hipLaunchKernelGGL(k_nms_reduce_csr, dim3((unsigned)batch), dim3(1024), 0, st, w.mask, w.order, counts, nmax, w.Np, w.W, w.ecap,
-                           w.cflag, w.boff, w.ekey, w.eval, quirk_drop_last, keep, keep_count);
+        hipLaunchKernelGGL(k_nms_reduce_csr<false>, dim3((unsigned)batch), dim3(1024), 0, st, w.mask, w.order, counts, nmax, w.Np, w.W, w.ecap,
+                           w.cflag, w.boff, w.ekey, w.eval, quirk_drop_last, keep, keep_count, hdr, (const u64 *)nullptr);
         // images whose compact form overflowed (dense masks); returns at once for the others
         {
             const size_t lds = (size_t)w.W * 16 + (size_t)PIPE_ROWS * PIPE_NEAR * 8;      // removed, removed1, 64 KB band
@@ -1079,7 +1631,7 @@ extern "C" int dg_nms_phase_reduce(const int32_t *counts, int64_t batch, int64_t
             const hipError_t attr = hipFuncSetAttribute((const void *)k_nms_reduce_band, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
             if (attr != hipSuccess) { dg_set_error("nms_reduce: cannot raise the LDS limit of k_nms_reduce_band: %s", hipGetErrorString(attr)); return DG_EHIP; }
             hipLaunchKernelGGL(k_nms_reduce_band, dim3((unsigned)batch), dim3(1024), lds, st, w.mask, w.order, counts, nmax,
-                               w.Np, w.W, quirk_drop_last, keep, keep_count, w.cflag);
+                               w.Np, w.W, quirk_drop_last, keep, keep_count, w.cflag, hdr);
         }
     }
     else if (w.W <= 4096) RED(1024, 4);
@@ -1098,6 +1650,22 @@ extern "C" int dg_nms_batched_f32(const float *boxes, const float *scores, const
     rc = dg_nms_phase_mask(counts, batch, nmax, threshold, ws, ws_bytes, s);
     if (rc) return rc;
     return dg_nms_phase_reduce(counts, batch, nmax, quirk_drop_last, keep, keep_count, ws, ws_bytes, s);
+}
+
+// diagnostic: which path image `img` of the last call on this workspace took (synchronous; tests and bench.py use it to
+// make sure a timing or a parity claim is about the path it names)
+extern "C" int dg_nms_path_info(const void *ws, size_t ws_bytes, int64_t batch, int64_t nmax, int64_t img, int32_t *out4_host)
+{
+    DG_REQUIRE(out4_host && img >= 0 && img < batch, "nms_path_info: bad argument");
+    NmsWs w;
+    int rc = nms_check("nms_path_info", batch, nmax, (void *)ws, ws_bytes, &w);
+    if (rc) return rc;
+    out4_host[0] = 1; out4_host[1] = 0; out4_host[2] = 0; out4_host[3] = 0;        // dense mask, no fixed point
+    if (batch == 0 || nmax == 0 || !w.pruned || nms_prune_mode() == 0) return DG_OK;
+    NmsHdr h;
+    if (hipMemcpy(&h, w.hdr + img, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) { dg_set_error("nms_path_info: copy failed"); return DG_EHIP; }
+    out4_host[0] = h.mode; out4_host[1] = h.fpdone; out4_host[2] = h.rounds; out4_host[3] = h.npairs;
+    return DG_OK;
 }
 
 // ---------------------------------------------------------------- allocation-free variant

@@ -54,6 +54,17 @@ def nms_workspace(dev, batch, nmax):
     return workspace(dev, nbytes), nbytes
 
 
+def nms_path_info(dev, batch, nmax, img=0):
+    """(mode, fpdone, rounds, npairs) of image `img` in the LAST NMS call that used this stream's workspace: mode 0 = pruned pair
+    search, 1 = dense mask; fpdone 1 = the fixed-point kernel produced the keep list.  Synchronous (diagnostic)."""
+    import ctypes as C
+    ws, nbytes = nms_workspace(dev, batch, nmax)
+    out = (C.c_int32 * 4)()
+    with torch.cuda.device(dev):
+        check(load().dg_nms_path_info(ptr(ws), nbytes, batch, nmax, img, out))
+    return tuple(out)
+
+
 def nms_batched(boxes, scores, counts=None, threshold=0.1, quirk_drop_last=True, keep=None, keep_count=None):
     """boxes (B,N,4) fp32, scores (B,N), counts (B) int32 or None -> keep (B,N) int64, keep_count (B) int32."""
     dev = _abi.device_of(boxes, scores)
