@@ -26,9 +26,7 @@ struct NmsHdr {
     int32_t fpdone;          // k_nms_resolve_fp converged and wrote the keep list
     int32_t rounds;          // rounds it took (diagnostic)
     int32_t npairs;          // suppressing pairs k_nms_band found (entries of the flat pair list; > ecap: overflow, mode -> 1)
-    int32_t xmin_i, xmax_i;  // min / max of x1 as order-preserving integers (k_nms_gather's atomics)
-    int32_t bad;             // a non-finite box was met
-    int32_t pad[7];
+    int32_t pad[10];
 };
 
 struct NmsWs {
@@ -89,8 +87,8 @@ static NmsWs nms_layout(int64_t batch, int64_t nmax, void *base)
         w.hdr = (struct NmsHdr *)take((size_t)batch * 64);
         w.bbox = (float4 *)take((size_t)batch * w.Np * 16);
         w.bar = (float2 *)take((size_t)batch * w.Np * 8);
-        w.pos = nullptr;
-        w.start = (int32_t *)take((size_t)batch * 4 * 4352 * 4);         // XB_STRIDE ints each: hist of x1 buckets, of x2 buckets, starts, cursors
+        w.pos = (int32_t *)take((size_t)batch * w.Np * 4);
+        w.start = (int32_t *)take((size_t)batch * (4096 + 1) * 4);       // XB_G + 1
         w.diag = (u64 *)take((size_t)batch * w.Np * 8);
     } else {
         w.hdr = nullptr; w.bbox = nullptr; w.bar = nullptr; w.pos = nullptr; w.start = nullptr; w.diag = nullptr;
@@ -110,10 +108,6 @@ __device__ __forceinline__ void gather_sorted(const float4 *__restrict__ boxes, 
     area[p] = dg_area(b.x, b.y, b.z, b.w);
     order[p] = idx;
 }
-
-// order-preserving int image of a float (and back): the pruned path's min / max of x1 by integer atomics
-__device__ __forceinline__ int32_t xb_ord(float x) { const int32_t b = __float_as_int(x); return b ^ ((b >> 31) & 0x7fffffff); }
-__device__ __forceinline__ float xb_unord(int32_t o) { return __int_as_float(o ^ ((o >> 31) & 0x7fffffff)); }
 
 // ---------------------------------------------------------------- sort, segments <= 4096
 template <int NP2, int T>
@@ -147,16 +141,11 @@ __global__ __launch_bounds__(T) void k_nms_sort_small(const float4 *__restrict__
 
 // ---------------------------------------------------------------- sort, long segments (global bitonic)
 __global__ __launch_bounds__(256) void k_nms_make_keys(const float *__restrict__ scores, const int32_t *__restrict__ counts,
-                                                       int64_t nmax, int64_t Np2, u64 *__restrict__ keys, NmsHdr *__restrict__ hdr,
-                                                       int32_t *__restrict__ xb)
+                                                       int64_t nmax, int64_t Np2, u64 *__restrict__ keys)
 {
     const int img = blockIdx.y;
     const int n = counts ? counts[img] : (int)nmax;
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (hdr) {                                               // pruned path: reset the image's header and its two bucket histograms
-        if (i == 0) { NmsHdr *h = hdr + img; h->mode = 1; h->fpdone = 0; h->rounds = 0; h->npairs = 0; h->xmin_i = 0x7fffffff; h->xmax_i = (int32_t)0x80000000; h->bad = 0; }
-        for (int64_t j = i; j < 2 * 4352; j += Np2) xb[(int64_t)img * 4 * 4352 + j] = 0;
-    }
     if (i < Np2) keys[(int64_t)img * Np2 + i] = (i < n) ? make_key(scores[(int64_t)img * nmax + i], (u32)i) : ~0ull;
 }
 
@@ -199,27 +188,13 @@ __global__ __launch_bounds__(256) void k_bitonic_global(u64 *__restrict__ keys, 
 
 __global__ __launch_bounds__(256) void k_nms_gather(const float4 *__restrict__ boxes, const u64 *__restrict__ keys,
                                                     const int32_t *__restrict__ counts, int64_t nmax, int64_t Np, int64_t Np2,
-                                                    float *x1, float *y1, float *x2, float *y2, float *area, int32_t *order,
-                                                    NmsHdr *__restrict__ hdr)
+                                                    float *x1, float *y1, float *x2, float *y2, float *area, int32_t *order)
 {
     const int img = blockIdx.y;
     const int n = counts ? counts[img] : (int)nmax;
     int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= Np) return;                                     // Np is a multiple of 64: whole waves leave
     gather_sorted(boxes + (int64_t)img * nmax, keys[(int64_t)img * Np2 + p], p < n, (int64_t)img * Np + p, x1, y1, x2, y2, area, order);
-    if (hdr) {                                               // pruned path: range of the left edges, non-finite boxes
-        const int64_t q = (int64_t)img * Np + p;
-        const bool valid = p < n;
-        int lo = valid ? xb_ord(x1[q]) : 0x7fffffff, hi = valid ? xb_ord(x1[q]) : (int32_t)0x80000000;
-        int bad = valid && !(area[q] < INFINITY);
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) { lo = min(lo, __shfl_xor(lo, d, 64)); hi = max(hi, __shfl_xor(hi, d, 64)); bad |= __shfl_xor(bad, d, 64); }
-        if ((threadIdx.x & 63) == 0) {
-            NmsHdr *h = hdr + img;
-            if (lo != 0x7fffffff) { atomicMin(&h->xmin_i, lo); atomicMax(&h->xmax_i, hi); }
-            if (bad) atomicOr(&h->bad, 1);
-        }
-    }
 }
 
 // ---------------------------------------------------------------- mask
@@ -1084,85 +1059,144 @@ __device__ __forceinline__ int xb_bucket(float x, float xmin, float scale)
     return (int)fminf(fmaxf((x - xmin) * scale, 0.0f), (float)(XB_G - 1));      // monotone in x; a NaN product (inf * 0) -> 0
 }
 
-#define XB_STRIDE 4352            // ints per array in the bucket workspace (XB_G + 1, padded)
-// the bucket scale of an image from the range k_nms_gather found (every thread recomputes it: two loads)
-__device__ __forceinline__ void xb_range(const NmsHdr *h, float *xmin, float *scale)
+// One workgroup per image (n <= 65536: at most 64 boxes per thread, their left edges stay in registers): range of the left
+// edges and non-finite boxes, bucket histogram in LDS, scan, every box's position in x-bucket order.  (Global-memory
+// atomics are not an option here: device-scope atomics are carried out at the memory side on this part, about 8 ns each
+// on one address -- a grid-wide histogram of 131 k of them took 25 us.)  The candidate-pair count that decides between this
+// path and the dense mask is estimated from 1024 boxes spread over the ranks.
+__global__ __launch_bounds__(1024) void k_nms_xbucket(const float *__restrict__ sx1, const float *__restrict__ sx2,
+                                                      const float *__restrict__ sarea, const int32_t *__restrict__ counts,
+                                                      int64_t nmax, int64_t Np, int force, NmsHdr *__restrict__ hdr,
+                                                      int32_t *__restrict__ start, int32_t *__restrict__ pos)
 {
-    const float mn = xb_unord(h->xmin_i), mx = xb_unord(h->xmax_i);
-    const float range = mx - mn;
-    float sc = (float)XB_G / range;
-    if (!(range > 0.0f) || !(sc < INFINITY)) sc = 0.0f;          // everything in bucket 0: the candidate count then says "dense"
-    *xmin = mn; *scale = sc;
-}
-
-// histogram of the left edges' buckets and of the right edges' (global atomics: 4096 counters in L2)
-__global__ __launch_bounds__(256) void k_nms_xb_hist(const float *__restrict__ sx1, const float *__restrict__ sx2,
-                                                     const int32_t *__restrict__ counts, int64_t nmax, int64_t Np,
-                                                     const NmsHdr *__restrict__ hdr, int32_t *__restrict__ xb)
-{
-    const int img = blockIdx.y;
-    const NmsHdr *h = hdr + img;
-    const int n = counts ? counts[img] : (int)nmax;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n || h->bad) return;
-    float mn, sc;
-    xb_range(h, &mn, &sc);
-    const float a = sx1[(int64_t)img * Np + i], b = sx2[(int64_t)img * Np + i];
-    int32_t *x = xb + (int64_t)img * 4 * XB_STRIDE;
-    atomicAdd(&x[xb_bucket(a, mn, sc)], 1);
-    atomicAdd(&x[XB_STRIDE + xb_bucket(fmaxf(a, b), mn, sc)], 1);   // an inverted box overlaps nothing; its range is empty
-}
-
-// one workgroup per image: bucket starts, the EXACT number of candidate pairs (for each box the boxes whose left edge
-// lies in the buckets its x range touches: sum_b hist2[b] * start[b + 1] - sum_b hist1[b] * start[b]) and with it the
-// decision between this path and the dense mask
-__global__ __launch_bounds__(1024) void k_nms_xb_scan(const int32_t *__restrict__ counts, int64_t nmax, int force,
-                                                      NmsHdr *__restrict__ hdr, int32_t *__restrict__ xb)
-{
-    __shared__ int s_part[16];
+    __shared__ int s_hist[XB_G];
+    __shared__ int s_start[XB_G + 1];
+    __shared__ float s_mn[16], s_mx[16];
+    __shared__ int s_bad[16], s_part[16];
     __shared__ unsigned long long s_cand;
     const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = counts ? counts[img] : (int)nmax;
+    const int64_t o = (int64_t)img * Np;
     NmsHdr *h = hdr + img;
-    int32_t *x = xb + (int64_t)img * 4 * XB_STRIDE;
+    float mn = INFINITY, mx = -INFINITY;
+    int bad = 0;
+    // a thread's boxes: the 16-byte chunks tid, tid + 1024, ... (four boxes each, at most 16 chunks), eight chunk loads in flight
+    const int nch = (n + 3) >> 2;
+#pragma unroll 1
+    for (int k0 = 0; k0 < 16 && tid + 1024 * k0 < nch; k0 += 8) {
+        float4 x[8], a[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = tid + 1024 * (k0 + u);
+            x[u] = c < nch ? *(const float4 *)(sx1 + o + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+            a[u] = c < nch ? *(const float4 *)(sarea + o + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = 4 * (tid + 1024 * (k0 + u));
+            const float xv[4] = {x[u].x, x[u].y, x[u].z, x[u].w}, av[4] = {a[u].x, a[u].y, a[u].z, a[u].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (i + q < n) { mn = fminf(mn, xv[q]); mx = fmaxf(mx, xv[q]); bad |= !(av[q] < INFINITY); }   // a non-finite coordinate makes the area inf or NaN
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { mn = fminf(mn, __shfl_xor(mn, d, 64)); mx = fmaxf(mx, __shfl_xor(mx, d, 64)); bad |= __shfl_xor(bad, d, 64); }
+    if (lane == 0) { s_mn[wave] = mn; s_mx[wave] = mx; s_bad[wave] = bad; }
+    for (int t = tid; t < XB_G; t += 1024) s_hist[t] = 0;
     if (tid == 0) s_cand = 0ull;
-    const int c0 = x[4 * tid], c1 = x[4 * tid + 1], c2 = x[4 * tid + 2], c3 = x[4 * tid + 3];
-    const int mine = c0 + c1 + c2 + c3;
-    int incl = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
-    if (lane == 63) s_part[wave] = incl;
     __syncthreads();
-    int base = 0;
-    for (int k = 0; k < wave; ++k) base += s_part[k];
-    const int e0 = base + incl - mine, e1 = e0 + c0, e2 = e1 + c1, e3 = e2 + c2, e4 = e3 + c3;
-    int32_t *st = x + 2 * XB_STRIDE, *cur = x + 3 * XB_STRIDE;
-    st[4 * tid] = e0; st[4 * tid + 1] = e1; st[4 * tid + 2] = e2; st[4 * tid + 3] = e3;
-    cur[4 * tid] = e0; cur[4 * tid + 1] = e1; cur[4 * tid + 2] = e2; cur[4 * tid + 3] = e3;
-    if (tid == 1023) st[XB_G] = e4;
-    const int32_t *h2 = x + XB_STRIDE;
-    long long cand = (long long)h2[4 * tid] * e1 + (long long)h2[4 * tid + 1] * e2 + (long long)h2[4 * tid + 2] * e3 + (long long)h2[4 * tid + 3] * e4
-                     - ((long long)c0 * e0 + (long long)c1 * e1 + (long long)c2 * e2 + (long long)c3 * e3);
 #pragma unroll
-    for (int d = 32; d > 0; d >>= 1) cand += __shfl_xor(cand, d, 64);
-    if (lane == 0) atomicAdd(&s_cand, (unsigned long long)cand);
+    for (int k = 0; k < 16; ++k) { mn = fminf(mn, s_mn[k]); mx = fmaxf(mx, s_mx[k]); bad |= s_bad[k]; }
+    if (bad || force == 0 || n <= 64) {                           // uniform
+        if (tid == 0) { h->xmin = 0.f; h->scale = 0.f; h->mode = 1; h->fpdone = 0; h->rounds = 0; h->npairs = 0; }
+        return;
+    }
+    const float range = mx - mn;
+    float scale = (float)XB_G / range;
+    if (!(range > 0.0f) || !(scale < INFINITY)) scale = 0.0f;    // everything in bucket 0: the candidate count then says "dense"
+#pragma unroll 1
+    for (int k0 = 0; k0 < 16 && tid + 1024 * k0 < nch; k0 += 8) {
+        float4 x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = tid + 1024 * (k0 + u);
+            x[u] = c < nch ? *(const float4 *)(sx1 + o + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = 4 * (tid + 1024 * (k0 + u));
+            const float xv[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (i + q < n) atomicAdd(&s_hist[xb_bucket(xv[q], mn, scale)], 1);
+        }
+    }
+    __syncthreads();
+    {   // exclusive scan of the 4096 counts: four per thread, wave scan, 16 wave totals
+        const int c0 = s_hist[4 * tid], c1 = s_hist[4 * tid + 1], c2 = s_hist[4 * tid + 2], c3 = s_hist[4 * tid + 3];
+        const int mine = c0 + c1 + c2 + c3;
+        int incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
+        if (lane == 63) s_part[wave] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int k = 0; k < wave; ++k) base += s_part[k];
+        int e = base + incl - mine;
+        int32_t *gs = start + (int64_t)img * (XB_G + 1);
+        s_start[4 * tid] = e; s_hist[4 * tid] = e; gs[4 * tid] = e; e += c0;
+        s_start[4 * tid + 1] = e; s_hist[4 * tid + 1] = e; gs[4 * tid + 1] = e; e += c1;
+        s_start[4 * tid + 2] = e; s_hist[4 * tid + 2] = e; gs[4 * tid + 2] = e; e += c2;
+        s_start[4 * tid + 3] = e; s_hist[4 * tid + 3] = e; gs[4 * tid + 3] = e;
+        if (tid == 0) { s_start[XB_G] = n; gs[XB_G] = n; }
+    }
+    __syncthreads();
+    const int nchp = (int)(Np >> 2);
+#pragma unroll 1
+    for (int k0 = 0; k0 < 16 && tid + 1024 * k0 < nchp; k0 += 8) {
+        float4 x[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = tid + 1024 * (k0 + u);
+            x[u] = c < nch ? *(const float4 *)(sx1 + o + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = tid + 1024 * (k0 + u), i = 4 * c;
+            if (c >= nchp) continue;
+            const float xv[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
+            int pv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)                          // the zero boxes of the padding stay behind the real ones
+                pv[q] = (i + q < n) ? atomicAdd(&s_hist[xb_bucket(xv[q], mn, scale)], 1) : i + q;
+            *(int4 *)(pos + o + i) = make_int4(pv[0], pv[1], pv[2], pv[3]);
+        }
+    }
+    {   // one sampled box per thread, spread over the ranks: the boxes whose left edge may lie inside its x range
+        const int i = (int)(((long long)tid * n) >> 10);
+        const float a = sx1[o + i], b = sx2[o + i];
+        const int c = s_start[xb_bucket(fmaxf(a, b), mn, scale) + 1] - s_start[xb_bucket(a, mn, scale)];
+        unsigned long long cand = (unsigned long long)(c > 0 ? c : 0);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) cand += __shfl_xor(cand, d, 64);
+        if (lane == 0) atomicAdd(&s_cand, cand);
+    }
     __syncthreads();
     if (tid == 0) {
-        float mn, sc;
-        xb_range(h, &mn, &sc);
-        // the band kernel tests about 1.8 x cand pairs (a row tile runs to the end of its widest box), the dense mask n^2 / 2
-        const bool prune = !h->bad && n > 64 && force != 0 &&
-                           (force == 2 || s_cand * 8ull <= (unsigned long long)n * (unsigned long long)n);
-        h->xmin = mn; h->scale = sc; h->mode = prune ? 0 : 1;
+        // candidates per box ~ s_cand / 1024; the band kernel tests about 1.8 x as many pairs (a row tile runs to the end of
+        // its widest box), the dense mask n / 2 per box
+        const bool prune = force == 2 || s_cand * 8ull <= 1024ull * (unsigned long long)n;
+        h->xmin = mn; h->scale = scale; h->mode = prune ? 0 : 1; h->fpdone = 0; h->rounds = 0; h->npairs = 0;
     }
 }
 
-// boxes into x-bucket order: bbox = corners, bar = {area, rank}; inside a bucket in the order the cursor hands out
-__global__ __launch_bounds__(256) void k_nms_xb_place(const float *__restrict__ sx1, const float *__restrict__ sy1,
-                                                      const float *__restrict__ sx2, const float *__restrict__ sy2,
-                                                      const float *__restrict__ sarea, const int32_t *__restrict__ counts,
-                                                      int64_t nmax, const NmsHdr *__restrict__ hdr, int64_t Np,
-                                                      int32_t *__restrict__ xb, float4 *__restrict__ bbox, float2 *__restrict__ bar)
+__global__ __launch_bounds__(256) void k_nms_xb_scatter(const float *__restrict__ sx1, const float *__restrict__ sy1,
+                                                        const float *__restrict__ sx2, const float *__restrict__ sy2,
+                                                        const float *__restrict__ sarea, const int32_t *__restrict__ pos,
+                                                        const int32_t *__restrict__ start, const int32_t *__restrict__ counts,
+                                                        int64_t nmax, const NmsHdr *__restrict__ hdr, int64_t Np,
+                                                        float4 *__restrict__ bbox, float2 *__restrict__ bar)
 {
     const int img = blockIdx.y;
     const NmsHdr *h = hdr + img;
@@ -1170,12 +1204,14 @@ __global__ __launch_bounds__(256) void k_nms_xb_place(const float *__restrict__ 
     const int n = counts ? counts[img] : (int)nmax;
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= Np) return;
-    const int64_t o = (int64_t)img * Np;
-    const float a = sx1[o + i];
-    int64_t p = i;                                               // the zero boxes of the padding stay behind the real ones
-    if (i < n) p = atomicAdd(&xb[(int64_t)img * 4 * XB_STRIDE + 3 * XB_STRIDE + xb_bucket(a, h->xmin, h->scale)], 1);
-    bbox[o + p] = make_float4(a, sy1[o + i], sx2[o + i], sy2[o + i]);
-    bar[o + p] = make_float2(sarea[o + i], __int_as_float((int)i));
+    const int64_t o = (int64_t)img * Np, p = o + pos[o + i];
+    const float a = sx1[o + i], b = sx2[o + i];
+    // with the rank (< 65536) goes the last 64-box tile of the x-bucket order that can hold a partner of this box: the one
+    // where the bucket of its right edge ends
+    int endtile = 0;
+    if (i < n) endtile = (start[(int64_t)img * (XB_G + 1) + xb_bucket(fmaxf(a, b), h->xmin, h->scale) + 1] - 1) >> 6;
+    bbox[p] = make_float4(a, sy1[o + i], b, sy2[o + i]);
+    bar[p] = make_float2(sarea[o + i], __int_as_float((int)i | (endtile << 16)));
 }
 
 __global__ void k_nms_force_dense(NmsHdr *__restrict__ hdr, int batch)
@@ -1210,15 +1246,11 @@ __global__ __launch_bounds__(256, 4) void k_nms_band(const float4 *__restrict__ 
     if (tid < 64) {
         const float4 b = bbox[o + t * 64 + tid];
         const float2 ar = bar[o + t * 64 + tid];
-        rbox[tid] = b; rarea[tid] = ar.x; rrank[tid] = __float_as_int(ar.y);
-        float x2 = (t * 64 + tid < n) ? b.z : -INFINITY;
+        rbox[tid] = b; rarea[tid] = ar.x; rrank[tid] = __float_as_int(ar.y) & 0xffff;
+        int jend = (t * 64 + tid < n) ? (int)((u32)__float_as_int(ar.y) >> 16) : 0;   // last column tile that can hold a partner
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) x2 = fmaxf(x2, __shfl_xor(x2, d, 64));
-        if (tid == 0) {
-            const int be = xb_bucket(x2, h->xmin, h->scale);
-            const int jend = (start[(int64_t)img * 4 * XB_STRIDE + 2 * XB_STRIDE + be + 1] - 1) >> 6;   // last column tile that can hold a partner
-            s_jend = jend > t ? jend : t;
-        }
+        for (int d = 32; d > 0; d >>= 1) jend = max(jend, __shfl_xor(jend, d, 64));
+        if (tid == 0) s_jend = jend > t ? jend : t;
     }
     __syncthreads();
     const int jend = s_jend;
@@ -1296,7 +1328,7 @@ __global__ __launch_bounds__(256, 4) void k_nms_band(const float4 *__restrict__ 
                 while (myword) {
                     const int c = __builtin_ctzll(myword);
                     myword &= myword - 1;
-                    const int cr = __float_as_int(cbar[(int64_t)j * 64 + c].y);
+                    const int cr = __float_as_int(cbar[(int64_t)j * 64 + c].y) & 0xffff;
                     const u32 lo = (u32)(rr < cr ? rr : cr), hi = (u32)(rr < cr ? cr : rr);
                     const u32 key = (lo << 16) | hi;               // ranks < 65536 (W <= 1024)
                     if (direct) { if (at < ecap) elist[at] = key; }
@@ -1326,9 +1358,12 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_fp(NmsHdr *__restrict__ hd
                                                          const int32_t *__restrict__ order, u64 *__restrict__ maskws, int max_rounds,
                                                          int quirk, int64_t *__restrict__ keep, int32_t *__restrict__ keep_count)
 {
-    __shared__ u64 K[1024], R[1024], R2[1024], Bk[1024];
+    // the bit sets as 32-bit words (32-bit shifts and LDS atomics); KEPT and REMOVED interleaved -- KR[2w] = kept bits of
+    // boxes 32w .. 32w+31, KR[2w+1] = removed bits -- so that a source's state is one 8-byte LDS read
+    __shared__ __attribute__((aligned(16))) u32 KR[4096];
+    __shared__ u32 R2[2048], Bk[2048];
     __shared__ int s_off[1024];
-    __shared__ int s_last, s_part[16];
+    __shared__ int s_last, s_part[16], s_live[2], s_cursor;
     const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     NmsHdr *h = hdr + img;
     if (h->mode != 0) return;
@@ -1338,42 +1373,122 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_fp(NmsHdr *__restrict__ hd
     elist += (int64_t)img * (ecap + CSR_SLACK);
     order += (int64_t)img * Np;
     keep += (int64_t)img * nmax;
-    u32 *wl[1];                                                  // the work list (ecap entries) lives in this image's unused dense mask
-    wl[0] = (u32 *)(maskws + (int64_t)img * Np * W);
-    const int64_t vb = (int64_t)tid * 64;
-    const u64 valid = (vb >= n) ? 0ull : ((n - vb >= 64) ? ~0ull : ((1ull << (n - vb)) - 1ull));   // of word `tid`
-    K[tid] = 0ull; R[tid] = 0ull; R2[tid] = 0ull; Bk[tid] = 0ull;
-    if (tid == 0) s_last = -1;
+    u32 *wlist = (u32 *)(maskws + (int64_t)img * Np * W);        // the work list (ecap entries) lives in this image's unused dense mask
+    u32 *wmine = wlist + 4 * tid;
+    u32 valid32[2];                                              // of the 32-bit words 2 tid, 2 tid + 1
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int vb = (2 * tid + q) * 32;
+        valid32[q] = (vb >= n) ? 0u : ((n - vb >= 32) ? ~0u : ((1u << (n - vb)) - 1u));
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) KR[4 * tid + q] = 0u;
+    R2[2 * tid] = 0u; R2[2 * tid + 1] = 0u; Bk[2 * tid] = 0u; Bk[2 * tid + 1] = 0u;
+    if (tid == 0) { s_last = -1; s_part[0] = 0; s_live[0] = 0; s_live[1] = 0; s_cursor = 0; }
+    // `order` is read at the very end, 64 dependent-free words per lane but from memory no cache of this CU's XCD holds (a
+    // round trip of about 2.4 us for this lone workgroup): one word of each of its 128-byte lines is loaded now, which
+    // brings the lines into the L2 the final loads will hit
+    const int pf0 = (tid * 32 < nb * 64) ? order[tid * 32] : 0, pf1 = ((tid + 1024) * 32 < nb * 64) ? order[(tid + 1024) * 32] : 0;
     __syncthreads();
+#ifdef DG_FP_STAMPS
+    if (tid == 0) ((long long *)(wlist + ecap))[61] = wall_clock64();
+#endif
     // round 0: boxes nothing suppresses are kept
-    for (int e0 = 0; e0 < E; e0 += 8 * 1024) {
-        u32 k[8];
+    for (int64_t c0 = 0; c0 * 4 < E; c0 += 8 * 1024) {
+        uint4 v[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int e = e0 + u * 1024 + tid; k[u] = e < E ? elist[e] : 0xffffffffu; }
+        for (int u = 0; u < 8; ++u) {
+            const int64_t c = c0 + u * 1024 + tid;
+            v[u] = (c * 4 < E) ? *(const uint4 *)(elist + 4 * c) : make_uint4(0, 0, 0, 0);
+        }
 #pragma unroll
-        for (int u = 0; u < 8; ++u)
-            if (k[u] != 0xffffffffu) atomicOr((unsigned long long *)&Bk[(k[u] & 0xffffu) >> 6], 1ull << (k[u] & 63u));   // lo < hi: never all ones
+        for (int u = 0; u < 8; ++u) {
+            const int64_t e = (c0 + u * 1024 + tid) * 4;
+            if (e < E) atomicOr(&Bk[(v[u].x & 0xffffu) >> 5], 1u << (v[u].x & 31u));
+            if (e + 1 < E) atomicOr(&Bk[(v[u].y & 0xffffu) >> 5], 1u << (v[u].y & 31u));
+            if (e + 2 < E) atomicOr(&Bk[(v[u].z & 0xffffu) >> 5], 1u << (v[u].z & 31u));
+            if (e + 3 < E) atomicOr(&Bk[(v[u].w & 0xffffu) >> 5], 1u << (v[u].w & 31u));
+        }
     }
     __syncthreads();
-    K[tid] = valid & ~Bk[tid];
-    Bk[tid] = 0ull;
-    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { KR[2 * (2 * tid + q)] = valid32[q] & ~Bk[2 * tid + q]; Bk[2 * tid + q] = 0u; }
     // Thread t owns the 16-byte chunks t, t + 1024, t + 2048, ... of the pair list (four entries each); the entries that
     // stay live it writes back to the same chunks of the work list, in order (in place from the second round on: the write
     // index never passes the read index), so no cursor, no atomics on memory, coalesced accesses and 32 entries in flight
     // per thread.  One entry: its source is KEPT -> mark the target REMOVED (and R2 if it already was), dead; REMOVED ->
-    // dead; undecided -> block the target for this round, live.  For the quirk every thread remembers the targets of the
-    // highest-ranked kept source it applied (the last kept box, if it has entries at all, is that for some thread).
+    // dead; undecided -> block the target for this round, live.  The sources' states of 16 entries are read together (one
+    // LDS round trip instead of 16; a REMOVED bit set meanwhile only costs the entry one more round).  For the quirk every
+    // thread remembers the targets of the highest-ranked kept source it applied (the last kept box, if it has entries at
+    // all, is that for some thread).
     const u32 *src_list = elist;
-    u32 *wlist = wl[0];
     int mycnt = 0;
     for (int64_t c = tid; c * 4 < E; c += 1024) mycnt += (E - c * 4 >= 4) ? 4 : (int)(E - c * 4);
     int rounds = 0, bsrc = -1, bn = 0;
     u64 bpack = 0;
     bool bail = false;
+#ifdef DG_FP_STAMPS
+    long long *dbg = (long long *)(wlist + ecap);
+    if (tid == 0) { dbg[0] = wall_clock64(); }
+#endif
     for (;;) {
-        if (!__syncthreads_or(mycnt > 0)) break;                 // no live entry anywhere: every box is decided
+#ifdef DG_FP_STAMPS
+        {
+            int c = mycnt;
+            for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
+            if (lane == 0) atomicAdd(&s_part[0], c);
+            __syncthreads();
+            if (tid == 0 && rounds < 30) { dbg[1 + 2 * rounds] = wall_clock64(); dbg[2 + 2 * rounds] = s_part[0]; s_part[0] = 0; }
+            __syncthreads();
+        }
+#endif
+        {   // live entries in all: none -> every box is decided; a handful -> the register-held rounds below
+            int c = mycnt;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
+            if (lane == 0 && c) atomicAdd(&s_live[rounds & 1], c);
+            if (tid == 0) s_live[(rounds + 1) & 1] = 0;
+            __syncthreads();
+        }
+        const int live = s_live[rounds & 1];
+        if (live == 0) break;
         if (rounds >= max_rounds) { bail = true; break; }
+        if (live <= 1024) {
+            // few entries left: one per thread, held in a register -- a round is two barriers and no memory traffic
+            int *small = s_off;                                  // (free until the keep list is written)
+            for (int p = 0; p < mycnt; ++p) small[atomicAdd(&s_cursor, 1)] = (int)src_list[4 * (tid + 1024 * (p >> 2)) + (p & 3)];
+            __syncthreads();
+            const u32 key = tid < live ? (u32)small[tid] : 0u;
+            const u32 src = key >> 16, dst = key & 0xffffu, sb = 1u << (src & 31), db = 1u << (dst & 31);
+            bool alive = tid < live;
+            for (;;) {
+                if (!__syncthreads_or(alive)) break;
+                if (rounds >= max_rounds) { bail = true; break; }
+                if (alive) {
+                    const uint2 kr = *(const uint2 *)&KR[2 * (src >> 5)];
+                    if (kr.x & sb) {
+                        const u32 old = atomicOr(&KR[2 * (dst >> 5) + 1], db);
+                        if (old & db) atomicOr(&R2[dst >> 5], db);
+                        if ((int)src > bsrc) { bsrc = (int)src; bn = 0; }
+                        if ((int)src == bsrc) { bpack = (bpack << 16) | dst; ++bn; }
+                        alive = false;
+                    } else if (kr.y & sb) {
+                        alive = false;
+                    } else {
+                        atomicOr(&Bk[dst >> 5], db);
+                    }
+                }
+                __syncthreads();
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int w = 2 * tid + q;
+                    KR[2 * w] |= valid32[q] & ~(KR[2 * w] | KR[2 * w + 1] | Bk[w]);
+                    Bk[w] = 0u;
+                }
+                ++rounds;
+            }
+            break;
+        }
         int out = 0;
         const int nch = (mycnt + 3) >> 2;
         for (int c0 = 0; c0 < nch; c0 += 8) {
@@ -1382,22 +1497,41 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_fp(NmsHdr *__restrict__ hd
             for (int u = 0; u < 8; ++u)
                 v[u] = (c0 + u < nch) ? *(const uint4 *)(src_list + 4 * (tid + 1024 * (c0 + u))) : make_uint4(0, 0, 0, 0);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int hh = 0; hh < 2; ++hh) {
+                u32 key[16];
+                uint2 kr[16];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const u32 key = q == 0 ? v[u].x : (q == 1 ? v[u].y : (q == 2 ? v[u].z : v[u].w));
-                    if ((c0 + u) * 4 + q >= mycnt) continue;
-                    const u32 src = key >> 16, dst = key & 0xffffu;
-                    const u64 sb = 1ull << (src & 63), db = 1ull << (dst & 63);
-                    if (K[src >> 6] & sb) {
-                        const u64 old = atomicOr((unsigned long long *)&R[dst >> 6], (unsigned long long)db);
-                        if (old & db) atomicOr((unsigned long long *)&R2[dst >> 6], (unsigned long long)db);
-                        if ((int)src > bsrc) { bsrc = (int)src; bn = 0; }
-                        if ((int)src == bsrc) { bpack = (bpack << 16) | dst; ++bn; }
-                    } else if (!(R[src >> 6] & sb)) {
-                        atomicOr((unsigned long long *)&Bk[dst >> 6], (unsigned long long)db);
-                        wlist[4 * (tid + 1024 * (out >> 2)) + (out & 3)] = key;
+                for (int i = 0; i < 16; ++i) {
+                    const uint4 vv = v[hh * 4 + (i >> 2)];
+                    key[i] = (i & 3) == 0 ? vv.x : ((i & 3) == 1 ? vv.y : ((i & 3) == 2 ? vv.z : vv.w));
+                    kr[i] = *(const uint2 *)&KR[2 * (key[i] >> 21)];
+                }
+                u32 old[16];                                     // the returning atomics of all 16 issued before the first is waited for
+                u32 applied = 0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    old[i] = 0u;
+                    if ((c0 + hh * 4) * 4 + i >= mycnt) continue;
+                    const u32 src = key[i] >> 16, dst = key[i] & 0xffffu;
+                    const u32 sb = 1u << (src & 31), db = 1u << (dst & 31);
+                    if (kr[i].x & sb) {
+                        old[i] = atomicOr(&KR[2 * (dst >> 5) + 1], db);
+                        applied |= 1u << i;
+                    } else if (!(kr[i].y & sb)) {
+                        atomicOr(&Bk[dst >> 5], db);
+                        wmine[((out >> 2) << 12) + (out & 3)] = key[i];
                         ++out;
+                    }
+                }
+                if (applied) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        if (!((applied >> i) & 1u)) continue;
+                        const int src = (int)(key[i] >> 16);
+                        const u32 dst = key[i] & 0xffffu, db = 1u << (dst & 31);
+                        if (old[i] & db) atomicOr(&R2[dst >> 5], db);
+                        if (src > bsrc) { bsrc = src; bn = 0; }
+                        if (src == bsrc) { bpack = (bpack << 16) | dst; ++bn; }
                     }
                 }
             }
@@ -1405,15 +1539,25 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_fp(NmsHdr *__restrict__ hd
         mycnt = out;
         src_list = wlist;
         __syncthreads();
-        if (tid < nb) { K[tid] |= valid & ~(K[tid] | R[tid] | Bk[tid]); Bk[tid] = 0ull; }      // what nothing blocks is kept
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {                            // what nothing blocks is kept
+            const int w = 2 * tid + q;
+            KR[2 * w] |= valid32[q] & ~(KR[2 * w] | KR[2 * w + 1] | Bk[w]);
+            Bk[w] = 0u;
+        }
         ++rounds;
     }
     if (bail) {                                                  // uniform: k_nms_reduce_csr<SEG> does this image from scratch
         if (tid == 0) { h->fpdone = 0; h->rounds = rounds; }
         return;
     }
-    // ---- K is final: count, quirk, keep list in rank order
-    const u64 kw = K[tid];
+#ifdef DG_FP_STAMPS
+    if (tid == 0) { dbg[63] = wall_clock64(); s_part[0] = 0; }
+    __syncthreads();
+#endif
+    // ---- the kept set is final: count, quirk, keep list in rank order
+    asm volatile("" ::"v"(pf0), "v"(pf1));                       // (the two prefetch loads of `order` end here)
+    const u64 kw = (u64)KR[4 * tid] | ((u64)KR[4 * tid + 2] << 32);      // kept bits of boxes 64 tid .. 64 tid + 63
     const int mine = __builtin_popcountll(kw);
     int incl = mine;
 #pragma unroll
@@ -1423,7 +1567,7 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_fp(NmsHdr *__restrict__ hd
     __syncthreads();
     int base = 0, total = 0;
     for (int k = 0; k < 16; ++k) { if (k < wave) base += s_part[k]; total += s_part[k]; }
-    s_off[tid] = base + incl - mine;                             // keep-list offset of word `tid`
+    s_off[tid] = base + incl - mine;                             // keep-list offset of 64-box word `tid`
     const int km = s_last;
     int drop = 0;
     if (quirk && total > 0) {                                    // uniform
@@ -1433,25 +1577,38 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_fp(NmsHdr *__restrict__ hd
         if (__syncthreads_or(own && bn > 4)) {
             for (int e = tid; e < E; e += 1024) {
                 const u32 key = elist[e];
-                if ((int)(key >> 16) == km) atomicOr((unsigned long long *)&Bk[(key & 0xffffu) >> 6], 1ull << (key & 63u));
+                if ((int)(key >> 16) == km) atomicOr(&Bk[(key & 0xffffu) >> 5], 1u << (key & 31u));
             }
         } else if (own) {
             for (int q = 0; q < bn; ++q) {
                 const u32 dst = (u32)(bpack >> (16 * q)) & 0xffffu;
-                atomicOr((unsigned long long *)&Bk[dst >> 6], 1ull << (dst & 63u));
+                atomicOr(&Bk[dst >> 5], 1u << (dst & 31u));
             }
         }
         __syncthreads();
-        drop = !__syncthreads_or((Bk[tid] & ~R2[tid]) != 0ull);  // none of them was left to it alone: nothing survived k1..k(m-1)
+        // none of them was left to it alone: nothing survived k1..k(m-1)
+        drop = !__syncthreads_or(((Bk[2 * tid] & ~R2[2 * tid]) | (Bk[2 * tid + 1] & ~R2[2 * tid + 1])) != 0u);
     } else {
         __syncthreads();
     }
-    for (int w = wave; w < nb; w += 16) {
-        u64 k = K[w];
-        if (drop && w == (km >> 6)) k &= ~(1ull << (km & 63));
-        if ((k >> lane) & 1ull) keep[s_off[w] + __builtin_popcountll(k & ((1ull << lane) - 1ull))] = (int64_t)order[w * 64 + lane];
+    for (int w0 = wave; w0 < nb; w0 += 16 * 8) {                 // eight 64-box words per wave pass, their `order` loads in flight together
+        int ord[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const int w = w0 + 16 * u; ord[u] = (w < nb) ? order[w * 64 + lane] : 0; }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int w = w0 + 16 * u;
+            if (w >= nb) continue;
+            u64 k = (u64)KR[4 * w] | ((u64)KR[4 * w + 2] << 32);
+            if (drop && w == (km >> 6)) k &= ~(1ull << (km & 63));
+            if ((k >> lane) & 1ull) keep[s_off[w] + __builtin_popcountll(k & ((1ull << lane) - 1ull))] = (int64_t)ord[u];
+        }
     }
     if (tid == 0) { keep_count[img] = total - drop; h->fpdone = 1; h->rounds = rounds; }
+#ifdef DG_FP_STAMPS
+    __syncthreads();
+    if (tid == 0) dbg[62] = wall_clock64();
+#endif
 }
 
 // ---------------------------------------------------------------- host
@@ -1508,8 +1665,7 @@ extern "C" int dg_nms_phase_sort(const float *boxes, const float *scores, const 
     case 4096: launch_sort_small<4096>(w, boxes, scores, counts, batch, nmax, st); break;
     default: {
         const int64_t Np2 = w.Np2;
-        hipLaunchKernelGGL(k_nms_make_keys, dim3((unsigned)(Np2 / 256), (unsigned)batch), dim3(256), 0, st, scores, counts, nmax, Np2, w.keys,
-                           prune ? w.hdr : (NmsHdr *)nullptr, w.start);
+        hipLaunchKernelGGL(k_nms_make_keys, dim3((unsigned)(Np2 / 256), (unsigned)batch), dim3(256), 0, st, scores, counts, nmax, Np2, w.keys);
         dim3 gl((unsigned)(Np2 / SORT_CHUNK), (unsigned)batch), gg((unsigned)(Np2 / 2 / 256), (unsigned)batch);
         hipLaunchKernelGGL(k_bitonic_lds, gl, dim3(1024), 0, st, w.keys, Np2, (int64_t)2, (int64_t)SORT_CHUNK, 1);
         for (int64_t k = 2 * SORT_CHUNK; k <= Np2; k <<= 1) {
@@ -1518,16 +1674,15 @@ extern "C" int dg_nms_phase_sort(const float *boxes, const float *scores, const 
             hipLaunchKernelGGL(k_bitonic_lds, gl, dim3(1024), 0, st, w.keys, Np2, k, k, SORT_CHUNK / 2);
         }
         hipLaunchKernelGGL(k_nms_gather, dim3((unsigned)dg_cdiv(w.Np, 256), (unsigned)batch), dim3(256), 0, st, (const float4 *)boxes,
-                           w.keys, counts, nmax, w.Np, Np2, w.x1, w.y1, w.x2, w.y2, w.area, w.order, prune ? w.hdr : (NmsHdr *)nullptr);
+                           w.keys, counts, nmax, w.Np, Np2, w.x1, w.y1, w.x2, w.y2, w.area, w.order);
     }
     }
     DG_CHECK_LAUNCH("nms sort");
     if (prune) {
-        hipLaunchKernelGGL(k_nms_xb_hist, dim3((unsigned)dg_cdiv(w.Np, 256), (unsigned)batch), dim3(256), 0, st, w.x1, w.x2, counts, nmax, w.Np,
-                           w.hdr, w.start);
-        hipLaunchKernelGGL(k_nms_xb_scan, dim3((unsigned)batch), dim3(1024), 0, st, counts, nmax, nms_prune_mode(), w.hdr, w.start);
-        hipLaunchKernelGGL(k_nms_xb_place, dim3((unsigned)dg_cdiv(w.Np, 256), (unsigned)batch), dim3(256), 0, st, w.x1, w.y1, w.x2, w.y2,
-                           w.area, counts, nmax, w.hdr, w.Np, w.start, w.bbox, w.bar);
+        hipLaunchKernelGGL(k_nms_xbucket, dim3((unsigned)batch), dim3(1024), 0, st, w.x1, w.x2, w.area, counts, nmax, w.Np,
+                           nms_prune_mode(), w.hdr, w.start, w.pos);
+        hipLaunchKernelGGL(k_nms_xb_scatter, dim3((unsigned)dg_cdiv(w.Np, 256), (unsigned)batch), dim3(256), 0, st, w.x1, w.y1, w.x2, w.y2,
+                           w.area, w.pos, w.start, counts, nmax, w.hdr, w.Np, w.bbox, w.bar);
         DG_CHECK_LAUNCH("k_nms_xbucket");
     }
     return DG_OK;
@@ -1554,7 +1709,8 @@ extern "C" int dg_nms_phase_mask(const int32_t *counts, int64_t batch, int64_t n
         if (!fast_ok) {
             hipLaunchKernelGGL(k_nms_force_dense, dim3((unsigned)dg_cdiv(batch, 256)), dim3(256), 0, (hipStream_t)s, w.hdr, (int)batch);
         } else {
-            const unsigned parts = (unsigned)(w.W >= 1024 ? 2 : (w.W >= 512 ? 4 : 8));
+            unsigned parts = (unsigned)(w.W >= 1024 ? 2 : (w.W >= 512 ? 4 : 8));
+            if (getenv("DG_NMS_BAND_PARTS")) parts = (unsigned)atoi(getenv("DG_NMS_BAND_PARTS"));
             const dim3 g(parts, (unsigned)w.W, (unsigned)batch);
             if (tie_even)
                 hipLaunchKernelGGL((k_nms_band<true>), g, dim3(256), 0, (hipStream_t)s, w.bbox, w.bar, w.start, w.hdr, counts, nmax, w.Np,
