@@ -1,5 +1,6 @@
-"""Parity at BASELINE.json's full sizes through size-independent properties (the oracle takes minutes to hours there).
-Every check goes through the product path (C ABI); torch on the GPU is only the checker."""
+"""Parity at BASELINE.json's full sizes: through size-independent properties, and (round 3) against the C oracle itself where
+it finishes in tens of seconds -- the 64k NMS keep lists, the 30-iteration fit on 10 M boxes, sampled rows of the 64k x 64k
+IoU matrix.  Every check goes through the product path (C ABI); torch on the GPU is only the checker."""
 import numpy as np
 import pytest
 import torch
@@ -207,3 +208,75 @@ def test_config3_full_size_batched_nms_256_images_vs_oracle(va, thr):
     for i, (b, s) in enumerate(props):
         want = orc.nms(b, s, thr)
         assert cnt[i] == len(want) and np.array_equal(keep[i, :cnt[i]], want), i
+
+
+# ---------------------------------------------------------------- round 3: the oracle itself at full size
+@pytest.mark.parametrize("dense,thr,quirk", [(False, 0.5, True), (False, 0.7, True), (False, 0.3, False), (True, 0.5, True), (True, 0.7, False)])
+def test_nms_64k_vs_oracle(va, dense, thr, quirk):
+    """config 5 (yolo/yolo_v1/yolo.py:188-203 on 65,536 boxes): the keep list, bit for bit, against the C oracle; sparse sets
+    take the pruned pair search + fixed-point keep list, dense ones the dense mask, and the test says which ran."""
+    from oracle import oracle as orc
+    from vision_amd import ops
+    orc.build()
+    b, s = wl.stress_boxes(0, 65536, dense=dense)
+    bt, st = torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()
+    keep, cnt = ops.nms_batched(bt[None], st[None], None, thr, quirk)
+    got = keep[0, :int(cnt[0])].cpu().numpy()
+    mode, fpdone, rounds, npairs = ops.nms_path_info(bt.device, 1, 65536)
+    assert mode == (1 if dense else 0), (mode, fpdone, rounds, npairs)
+    if not dense:
+        assert fpdone == 1 and 0 < rounds < 64 and npairs > 0
+    want = orc.nms(b, s, thr, quirk)
+    assert len(got) == len(want) and np.array_equal(got, want)
+
+
+def test_nms_64k_fallbacks_vs_oracle(va, monkeypatch):
+    """The same 64k sparse set through the pruned path's serial fallback (the fixed point cut off after 2 rounds) and with
+    the pruned path forced onto dense boxes: same keep lists as the oracle."""
+    from oracle import oracle as orc
+    from vision_amd import ops
+    orc.build()
+    b, s = wl.stress_boxes(0, 65536, dense=False)
+    bt, st = torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()
+    want = orc.nms(b, s, 0.5, True)
+    monkeypatch.setenv("DG_NMS_FP_ROUNDS", "2")
+    keep, cnt = ops.nms_batched(bt[None], st[None], None, 0.5, True)
+    assert ops.nms_path_info(bt.device, 1, 65536)[:2] == (0, 0)
+    assert np.array_equal(keep[0, :int(cnt[0])].cpu().numpy(), want)
+    monkeypatch.delenv("DG_NMS_FP_ROUNDS")
+    monkeypatch.setenv("DG_NMS_PRUNE", "2")
+    b, s = wl.stress_boxes(0, 65536, dense=True)
+    bt, st = torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()
+    keep, cnt = ops.nms_batched(bt[None], st[None], None, 0.7, True)
+    assert ops.nms_path_info(bt.device, 1, 65536)[:2] == (0, 1)
+    assert np.array_equal(keep[0, :int(cnt[0])].cpu().numpy(), orc.nms(b, s, 0.7, True))
+
+
+def test_pairwise_64k_rows_vs_oracle(va):
+    """config 5: 2,048 sampled rows of the 64k x 64k IoU matrix (yolo/yolo_v1/modules.py:73-98 per entry), bit for bit."""
+    from oracle import oracle as orc
+    from vision_amd import ops
+    orc.build()
+    b, _ = wl.stress_boxes(0, 65536, dense=True)
+    bt = torch.from_numpy(b).cuda()
+    m = ops.iou_pairwise(bt, bt)
+    rows = np.sort(np.random.default_rng(5).choice(65536, 2048, replace=False))
+    got = m[torch.from_numpy(rows).cuda()].cpu().numpy()
+    want = orc.iou_pairwise(b[rows], b)
+    assert got.shape == want.shape and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_kmeans_10m_fit30_vs_oracle(va):
+    """config 4 as bench.py times it: kmean(5, 42).fit(wh_10M, fixed_iters=30) against the oracle's 30 Lloyd iterations --
+    labels, centroids, inertia, bit for bit (integer sums; spec in oracle.c, no reference counterpart: parity unpinned)."""
+    from oracle import oracle as orc
+    from vision_amd.cluster import kmean
+    orc.build()
+    wh = wl.anchor_wh(0, 10_000_000)
+    km = kmean(n_clusters=5, random_state=42).fit(torch.from_numpy(wh).cuda(), fixed_iters=30)
+    cent, labels, n_iter, inertia = orc.kmeans_fit(wh, 5, 42, fixed_iters=30)
+    assert km.n_iter_ == n_iter == 30
+    assert np.array_equal(np.asarray(km.cluster_centers_, np.float32).view(np.uint32), cent.view(np.uint32))
+    got_labels = km.labels_.cpu().numpy() if isinstance(km.labels_, torch.Tensor) else np.asarray(km.labels_)
+    assert np.array_equal(got_labels.astype(np.int32), labels)
+    assert float(km.inertia_) == inertia

@@ -33,7 +33,9 @@ def _both(lib, _abi, ops, boxes, scores, counts, thr, quirk):
 
 
 def test_nms_noalloc_matches_workspace_entry_point():
+    from oracle import oracle as orc
     from vision_amd import _abi, ops
+    orc.build()
     lib = _abi.load()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
@@ -50,6 +52,9 @@ def test_nms_noalloc_matches_workspace_entry_point():
         assert c0.min() >= 0
         for i in range(B):
             assert np.array_equal(k0[i, :c0[i]], k1[i, :c1[i]]), (B, N, i)
+            ni = N - 137 * i if ragged else N                     # and both against the oracle (yolo/yolo_v1/yolo.py:188-203)
+            want = orc.nms(bs[i][0][:ni], bs[i][1][:ni], thr, bool(quirk))
+            assert np.array_equal(k1[i, :c1[i]], want), (B, N, i)
 
 
 def test_nms_noalloc_rejects_oversize():
@@ -67,11 +72,13 @@ def test_nms_noalloc_rejects_oversize():
 def test_nms_noalloc_under_graph_capture():
     """The callers the entry point is for: a HIP graph capture, where hipMalloc is not allowed.  Captured once, replayed
     on new boxes written into the same buffers; sparse and dense boxes (both reduce kernels)."""
+    from oracle import oracle as orc
     from vision_amd import _abi, ops
+    orc.build()
     lib = _abi.load()
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    for n, dense, thr in ((2000, False, 0.5), (3000, True, 0.5)):
+    for n, dense, thr in ((2000, False, 0.5), (3000, True, 0.5), (6000, False, 0.5)):
         boxes = torch.zeros((1, n, 4), dtype=torch.float32, device=dev)
         scores = torch.zeros((1, n), dtype=torch.float32, device=dev)
         keep = torch.zeros((1, n), dtype=torch.int64, device=dev)
@@ -96,3 +103,4 @@ def test_nms_noalloc_under_graph_capture():
             k1, c1 = ops.nms_batched(boxes, scores, None, thr, True)
             assert int(kc.item()) == int(c1.item())
             assert torch.equal(keep[0, :int(kc.item())], k1[0, :int(c1.item())])
+            assert np.array_equal(keep[0, :int(kc.item())].cpu().numpy(), orc.nms(b, s, thr, True))
