@@ -450,7 +450,8 @@ PARTIAL = {}          # side results a section publishes before a step that coul
 
 def start_watchdog(d, line, extra, seconds):
     """The side configurations run after the primary measurement.  Should one of them hang (a collective that never
-    returns, say), every rank leaves after `seconds`: rank 0 prints the primary line with what the extras had produced."""
+    returns, say), every rank leaves after `seconds`: rank 0 prints the primary line with what the extras had produced and
+    `"extras_hung": true`, and every rank exits with status 3 (the hang stays visible to the driver)."""
     import threading
 
     def fire():
@@ -462,6 +463,7 @@ def start_watchdog(d, line, extra, seconds):
                 ex["watchdog"] = f"side configurations did not finish within {seconds} s; primary line printed by the watchdog"
                 out = dict(line)
                 out["extra"] = ex
+                out["extras_hung"] = True
                 out.setdefault("roofline", None)
                 out.setdefault("cpu_baseline", None)
                 sys.stdout.write(json.dumps(out, default=str) + "\n")
@@ -470,7 +472,7 @@ def start_watchdog(d, line, extra, seconds):
         except BaseException as e:  # noqa: BLE001
             print(f"[bench rank {d.rank}] watchdog failed to print the line: {e!r}", file=sys.stderr, flush=True)
         finally:
-            os._exit(0)
+            os._exit(3)      # the primary line is out, but a hang in the side configurations must not look like a clean run
     t = threading.Timer(seconds, fire)
     t.daemon = True
     t.start()

@@ -34,6 +34,7 @@ import torch.nn as nn
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from tools import workloads as wl  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
 
 REF = os.environ.get("REFERENCE_ROOT", "/root/reference")
 OUT = os.path.join(ROOT, "tests", "golden")
@@ -95,7 +96,7 @@ def _loss_inputs(seed, batch, num_classes, objects_per_image):
         for _ in range(objects_per_image):
             xy = rng.uniform(0.02, 0.6, 2); wh = rng.uniform(0.05, 0.38, 2)
             lab = int(rng.integers(1, num_classes + 1))
-            t = wl.yolo1_encode(np.concatenate([xy, wh]), lab, num_classes).astype(np.float32)
+            t = orc.yolo1_encode(np.concatenate([xy, wh]), lab, num_classes).astype(np.float32)
             cell = t[..., 4] > 0
             tgt[b][cell] = t[cell]
     # a few object cells whose predictions sit far from the target: both IoUs 0 (tie -> slot 1 is responsible)
@@ -263,7 +264,7 @@ def gen_decode():
     for _ in range(20):
         bb = np.concatenate([rng.uniform(0.05, 0.6, 2), rng.uniform(0.05, 0.35, 2)])
         lab = int(rng.integers(1, 6))
-        assert np.array_equal(ns["encode"](bb.copy(), lab, 5), wl.yolo1_encode(bb, lab, 5))
+        assert np.array_equal(ns["encode"](bb.copy(), lab, 5), orc.yolo1_encode(bb, lab, 5))
 
     out, tgt = wl.yolo1_batch(0, batch=16)
     d = {"output": out, "target": tgt}

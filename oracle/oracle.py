@@ -11,13 +11,15 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "liboracle.so")
+_SO = os.environ.get("ORACLE_SO") or os.path.join(_HERE, "liboracle.so")      # ORACLE_SO: e.g. the sanitizer build (make asan)
 
 OK, EINVAL, EEMPTYROI, EASSERT = 0, -1, -2, -3
 
 
 def build(force=False):
     src = os.path.join(_HERE, "oracle.c")
+    if os.environ.get("ORACLE_SO"):
+        return _SO
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-s", "-C", _HERE, "liboracle.so"])
     return _SO
@@ -285,6 +287,24 @@ def average_precision(detects, targets, iou_thr=0.01):
             ap += (recall[i + 1] - recall[i]) * prec[i + 1]
         aps.append(ap)
     return aps
+
+
+# ------------------------------------------------------------------ YOLOv1 target builder
+def yolo1_encode(bb, label, num_classes, S=7, B=2):
+    """encode(bb, label, num_classes): yolo/yolo_v1/modules.py:151-174, float64 like the reference (NumPy restatement;
+    pinned by tests/golden/yolo1_encode.npz, which the reference's own encode produced)."""
+    bb = np.asarray(bb, np.float64).copy()
+    N = 5 * B + num_classes
+    bb[:2] += bb[2:] / 2                                         # :156 centre
+    t = np.zeros((S, S, N))
+    cxy, wh = bb[:2], bb[2:]
+    ij = (cxy * S).astype(int)                                   # :160
+    i, j = ij
+    xy_cell = (cxy - ij * (1 / S)) / (1 / S)                     # :163-164
+    for b in range(B):
+        t[j, i, b * 5:(b + 1) * 5] = np.hstack([xy_cell, wh, 1])
+    t[j, i, B * 5 + label - 1] = 1
+    return t
 
 
 # ------------------------------------------------------------------ anchor k-means (spec in oracle.c)

@@ -684,7 +684,7 @@ def test_roipool_other_output_sizes_golden(va, golden):
 
 
 @pytest.mark.parametrize("H,W,P,mode", [(300, 260, 7, "max"), (300, 260, 7, "avg"), (150, 200, 7, "max"), (130, 120, 7, "avg"),
-                                        (300, 260, (4, 6), "max"), (38, 50, 5, "max")])
+                                        (300, 260, (4, 6), "max"), (38, 50, 5, "max"), (200, 250, 7, "max"), (200, 250, 7, "avg")])
 def test_roipool_large_maps_and_sizes_vs_oracle(va, oracle, H, W, P, mode):
     """maps beyond the tuned kernels' limits (forward: 65535 cells; backward plane in LDS: 32768 cells in max mode, 14336 in
     avg mode) and other output sizes, forward and backward against the oracle."""
@@ -710,6 +710,29 @@ def test_roipool_large_maps_and_sizes_vs_oracle(va, oracle, H, W, P, mode):
     gin = ops.roipool_backward(torch.from_numpy(gout).to(dev), arg, win, img.shape, mode, P=P).cpu().numpy()
     want = oracle.roipool_bwd(gout, warg, img.shape, rois, idx, P, mode)
     np.testing.assert_allclose(gin, want, rtol=1e-4, atol=1e-4)
+
+
+def test_roipool_band_tuned_forward_generic_backward(va, oracle):
+    """32768 < H*W <= 65535 in max mode: the tuned forward (uint16 argmax under autograd) paired with the generic
+    global-atomic backward, which then reads a 16-bit index -- through slowroipool with requires_grad, against the oracle."""
+    from vision_amd import fast_rcnn
+    H, W = 200, 250
+    rng = np.random.default_rng(50000)
+    B, C = 2, 6
+    img = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    n = 80
+    xy = rng.uniform(0, 0.9, (n, 2)); wh = rng.uniform(0.004, 0.09, (n, 2))        # crops of 1..23 cells: the tuned strips' widths
+    rois = np.concatenate([xy, xy + wh], 1)
+    rois[0] = [0.0, 0.0, 0.05, 1.0]                                                 # the full height: argmax up to 49,999 (> int16)
+    idx = rng.integers(0, B, n).astype(np.int64)
+    want, warg = oracle.roipool_fwd(img, rois, idx, 7, "max")
+    assert warg.max() > 40000
+    x = torch.from_numpy(img).cuda().requires_grad_(True)
+    y = fast_rcnn.slowroipool(7, mode="max").foward(x, rois, idx)
+    assert np.array_equal(y.detach().cpu().numpy(), want)
+    gout = rng.standard_normal(want.shape).astype(np.float32)
+    y.backward(torch.from_numpy(gout).cuda())
+    np.testing.assert_allclose(x.grad.cpu().numpy(), oracle.roipool_bwd(gout, warg, img.shape, rois, idx, 7, "max"), rtol=1e-4, atol=1e-4)
 
 
 def test_roipool_odd_channels_and_batch(va, oracle):

@@ -189,11 +189,19 @@ def test_yolo1_loss_oracle_vs_reference(golden, oracle):
         assert abs((5 * (comp[0] + comp[1]) + comp[2] + 0.5 * comp[3] + comp[4]) / n - loss) <= 1e-6 * loss
 
 
-def test_yolo1_encode_restatement_vs_reference(golden):
-    """workloads.yolo1_encode (the NumPy restatement used for synthetic targets) against the reference's encode."""
+def test_yolo1_encode_restatement_vs_reference(golden, oracle):
+    """oracle.yolo1_encode (the NumPy restatement) against the reference's encode, and the synthetic one-object targets of
+    tools/workloads.yolo1_batch against it."""
     from tools import workloads as wl
     g = golden("yolo1_encode")
     for k in range(len(g["bb"])):
         C = 5 if k < 30 else 20
         want = g["target_c5"][k] if k < 30 else g["target_c20"][k - 30]
-        assert np.array_equal(wl.yolo1_encode(g["bb"][k], int(g["label"][k]), C), want), k
+        assert np.array_equal(oracle.yolo1_encode(g["bb"][k], int(g["label"][k]), C), want), k
+    # the one-object targets workloads.yolo1_batch builds for bench.py and the decode tests are what encode would build
+    rng = np.random.default_rng(77)
+    _, tgt = wl.yolo1_batch(77, batch=16, num_classes=5)
+    rng.uniform(0, 1, (16, 7, 7, 15))                             # (the generator draws the predictions first)
+    for b in range(16):
+        xy = rng.uniform(0.05, 0.6, 2); wh = rng.uniform(0.05, 0.35, 2); lab = int(rng.integers(1, 6))
+        assert np.array_equal(tgt[b], oracle.yolo1_encode(np.concatenate([xy, wh]), lab, 5).astype(np.float32)), b

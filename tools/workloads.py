@@ -48,23 +48,6 @@ def frcnn_proposals(seed, n=2000):
 
 
 # ---------------------------------------------------------------- config 2
-def yolo1_encode(bb, label, num_classes, S=7, B=2):
-    """Target builder used only to make synthetic `target` tensors with one object
-    cell (same layout the reference's encode produces, modules.py:151-174)."""
-    bb = np.asarray(bb, np.float64).copy()
-    N = 5 * B + num_classes
-    bb[:2] += bb[2:] / 2
-    t = np.zeros((S, S, N))
-    cxy, wh = bb[:2], bb[2:]
-    ij = (cxy * S).astype(int)
-    i, j = ij
-    xy_cell = (cxy - ij * (1 / S)) / (1 / S)
-    for b in range(B):
-        t[j, i, b * 5:(b + 1) * 5] = np.hstack([xy_cell, wh, 1])
-    t[j, i, B * 5 + label - 1] = 1
-    return t
-
-
 def yolo1_batch(seed, batch=64, num_classes=5, one_slot=False):
     """output ~ U(0,1) (sigmoid range) (batch,7,7,10+C) fp32 and a one-object target.
 
@@ -78,12 +61,20 @@ def yolo1_batch(seed, batch=64, num_classes=5, one_slot=False):
         dead = rng.integers(0, 2, (batch, 7, 7))
         out[..., 4][dead == 0] = 0.0
         out[..., 9][dead == 1] = 0.0
+    # one-object targets in the layout decode() expects (yolo/yolo_v1/yolo.py:133-152): the object's cell carries, in both
+    # box slots, the centre's offset inside the cell in cell units, the size and confidence 1, plus a one-hot class
+    # (draw order per image: corner, size, label)
     tgt = np.zeros_like(out)
     for b in range(batch):
         xy = rng.uniform(0.05, 0.6, 2)
         wh = rng.uniform(0.05, 0.35, 2)
         lab = int(rng.integers(1, num_classes + 1))
-        tgt[b] = yolo1_encode(np.concatenate([xy, wh]), lab, num_classes).astype(np.float32)
+        centre = xy + wh / 2
+        col, row = (centre * 7).astype(int)
+        slot = np.concatenate([(centre - np.array([col, row]) * (1 / 7)) / (1 / 7), wh, [1.0]])
+        tgt[b, row, col, 0:5] = slot
+        tgt[b, row, col, 5:10] = slot
+        tgt[b, row, col, 10 + lab - 1] = 1
     return out, tgt
 
 

@@ -285,11 +285,24 @@ class kmean:
             self._comm.close()
             self._comm, self._own_comm = None, False
 
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     def __del__(self):
-        try:
-            self.close()
-        except Exception:  # noqa: BLE001
-            pass
+        # destroying an RCCL communicator is collective: a finalizer runs at a different moment on every rank (GC order,
+        # interpreter shutdown, after the process group or librccl itself is gone), so it is NOT done here.  Call close()
+        # on every rank, or use the object as a context manager; a communicator left open is only reported.
+        if getattr(self, "_own_comm", False) and getattr(self, "_comm", None) is not None:
+            try:
+                import warnings
+                warnings.warn("vision_amd.cluster.kmean: the library-side communicator was not closed (call close() on every "
+                              "rank); it is left to process exit", ResourceWarning, stacklevel=2)
+            except Exception:  # noqa: BLE001
+                pass
 
     def _run_so(self, comm, slot0, count):
         be = self._backend

@@ -636,10 +636,18 @@ extern "C" int dg_kmeans_iou_run_sharded(dg_comm_t *c, const float *wh, int64_t 
     hipGraphExec_t ex = nullptr;
     if (rc == DG_OK && e == hipSuccess && g) e = hipGraphInstantiate(&ex, g, nullptr, nullptr, 0);
     if (g) (void)hipGraphDestroy(g);
-    if (rc != DG_OK || e != hipSuccess || !ex) {
+    if (rc != DG_OK) {
+        // a launch or an RCCL call failed WHILE capturing: the communicator may be in an error state, so nothing is re-issued on
+        // it -- the error goes to the caller (dg_last_error holds its text), and the handle stays eager from now on
+        (void)hipGetLastError();
+        if (ex) (void)hipGraphExecDestroy(ex);
+        c->graph_state = -1;
+        return rc;
+    }
+    if (e != hipSuccess || !ex) {
         (void)hipGetLastError();
         c->graph_state = -1;
-        if (rc == DG_OK) dg_set_error("kmeans_run_sharded: capture failed (%s), issuing eagerly", hipGetErrorString(e));
+        dg_set_error("kmeans_run_sharded: capture failed (%s), issuing eagerly", hipGetErrorString(e));
         return km_sharded_issue(c, wh, n, cent, k, labels, acc, history, slot0, iters, ws, st);   // nothing ran during the capture
     }
     c->graph_exec = ex;
