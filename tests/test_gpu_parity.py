@@ -109,6 +109,79 @@ def test_nms_band_reduce_forced_vs_oracle(va, oracle, dense, monkeypatch):
                 assert cnt[i] == len(want) and np.array_equal(keep[i, :cnt[i]], want), (n, thr, quirk, i)
 
 
+@pytest.mark.parametrize("fb", ["0", "2"])
+def test_nms_small_image_rounds_and_serial_vs_oracle(va, oracle, fb, monkeypatch):
+    """k_nms_resolve_small (images of 449 .. 4096 boxes: the non-zero mask words in LDS, the boxes decided in rounds): sparse
+    and dense sets, ragged batches, both quirk settings, a chain that needs hundreds of rounds (so the round limit hands over to
+    the serial chain), a mask with more non-zero words than the LDS holds (ditto), and with DG_NMS_FORCE_FALLBACK=2 every
+    image through that in-kernel serial chain; against the oracle."""
+    from vision_amd import ops
+    monkeypatch.setenv("DG_NMS_FORCE_FALLBACK", fb)
+    cases = []
+    for n, dense, thr in ((449, False, 0.5), (700, True, 0.3), (2000, False, 0.7), (2000, True, 0.3), (4096, True, 0.1), (4096, False, 0.6)):
+        bb = np.stack([wl.stress_boxes(500 + n + i, n, dense=dense)[0] for i in range(3)])
+        ss = np.stack([wl.stress_boxes(500 + n + i, n, dense=dense)[1] for i in range(3)])
+        cases.append((bb, ss, np.array([n, max(n - 70, 1), min(450, n - 1)], np.int32), thr))
+    b, s = wl.frcnn_proposals(1, 2000)
+    cases.append((b[None], s[None], None, 0.7)); cases.append((b[None], s[None], None, 0.3))
+    m = 3000                                                     # a ladder: every box suppresses exactly the next one
+    x = np.arange(m, dtype=np.float32) * 0.45
+    lad = np.stack([x, np.zeros(m, np.float32), x + 1.0, np.ones(m, np.float32)], 1)
+    cases.append((lad[None], np.linspace(1, 0.1, m, dtype=np.float32)[None], None, 0.3))
+    for boxes, scores, counts, thr in cases:
+        for quirk in (True, False):
+            keep, cnt = ops.nms_batched(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(),
+                                        torch.from_numpy(counts) if counts is not None else None, thr, quirk)
+            keep, cnt = keep.cpu().numpy(), cnt.cpu().numpy()
+            for i in range(boxes.shape[0]):
+                ni = counts[i] if counts is not None else boxes.shape[1]
+                want = oracle.nms(boxes[i, :ni], scores[i, :ni], thr, quirk)
+                assert cnt[i] == len(want) and np.array_equal(keep[i, :cnt[i]], want), (boxes.shape, thr, quirk, i)
+
+
+@pytest.mark.parametrize("prune,rounds", [("1", None), ("2", None), ("2", "0"), ("2", "1"), ("2", "3"), ("0", None)])
+def test_nms_pruned_path_vs_oracle(va, oracle, prune, rounds, monkeypatch):
+    """The pruned path of large images (x-bucket band pair search, flat pair list, fixed-point keep list) and its fallbacks:
+    DG_NMS_PRUNE=2 takes it whatever the candidate count, DG_NMS_FP_ROUNDS cuts the fixed point off after that many rounds
+    (the serial chain over the grouped pair list finishes), 0 = the dense mask only.  Sparse and dense sets, degenerate
+    boxes, ragged batches, a ladder (one round per box), identical boxes (every pair suppresses); against the oracle."""
+    from vision_amd import ops
+    monkeypatch.setenv("DG_NMS_PRUNE", prune)
+    if rounds is not None:
+        monkeypatch.setenv("DG_NMS_FP_ROUNDS", rounds)
+    cases = []
+    for n, dense in ((20000, False), (9000, True), (4200, False), (5000, True)):
+        b, s = wl.stress_boxes(3 + n, n, dense=dense)
+        cases.append((b[None], s[None], None))
+    cases.append((wl.random_boxes(5, 9000)[None], wl.tiefree_scores(6, 9000)[None], None))
+    bb = np.stack([wl.stress_boxes(40 + i, 6000)[0] for i in range(3)]); ss = np.stack([wl.stress_boxes(40 + i, 6000)[1] for i in range(3)])
+    cases.append((bb, ss, np.array([6000, 4500, 4100], np.int32)))
+    m = 5000
+    x = np.arange(m, dtype=np.float32) * 0.45
+    cases.append((np.stack([x, np.zeros(m, np.float32), x + 1.0, np.ones(m, np.float32)], 1)[None], np.linspace(1, 0.1, m, dtype=np.float32)[None], None))
+    cases.append((np.tile(np.array([[0.1, 0.1, 0.5, 0.5]], np.float32), (4500, 1))[None], wl.tiefree_scores(9, 4500)[None], None))
+    nf = wl.stress_boxes(8, 6000)[0].copy(); nf[17, 2] = np.inf; nf[3000] = np.nan                 # non-finite boxes: dense mask
+    cases.append((nf[None], wl.tiefree_scores(10, 6000)[None], None))
+    for boxes, scores, counts in cases:
+        bt, st = torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda()
+        ct = torch.from_numpy(counts) if counts is not None else None
+        for thr in (0.3, 0.6):
+            for quirk in (True, False):
+                keep, cnt = ops.nms_batched(bt, st, ct, thr, quirk)
+                keep, cnt = keep.cpu().numpy(), cnt.cpu().numpy()
+                info = ops.nms_path_info(bt.device, boxes.shape[0], boxes.shape[1])
+                if prune == "0" or not np.isfinite(boxes).all():
+                    assert info[0] == 1, info
+                elif prune == "2":
+                    assert info[0] == 0 or info[3] > 32 * boxes.shape[1], info      # pruned unless the pair list overflowed
+                    if info[0] == 0 and rounds == "0" and info[3] > 0:
+                        assert info[1] == 0, info                                   # the serial chain finished the image
+                for i in range(boxes.shape[0]):
+                    ni = counts[i] if counts is not None else boxes.shape[1]
+                    want = oracle.nms(boxes[i, :ni], scores[i, :ni], thr, quirk)
+                    assert cnt[i] == len(want) and np.array_equal(keep[i, :cnt[i]], want), (boxes.shape, thr, quirk, i, info)
+
+
 def test_nms_threshold_edges_vs_oracle(va, oracle):
     """The mask phase tests inter/den < thr without dividing: thresholds that are exactly an IoU value of the set,
     its float neighbours, 0, negatives, inf and NaN must all give the oracle's (dividing) answer."""

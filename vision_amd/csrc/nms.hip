@@ -122,8 +122,15 @@ __global__ __launch_bounds__(T) void k_nms_sort_small(const float4 *__restrict__
     scores += (int64_t)img * nmax;
     for (int i = tid; i < NP2; i += T) keys[i] = (i < n) ? make_key(scores[i], (u32)i) : ~0ull;
     __syncthreads();
+    // A wave's 64 pair indices t touch one 128-key block as long as j <= 64, and the same block in every such step: those
+    // steps need no workgroup barrier (LDS operations of one wave complete in order), only the steps that cross waves
+    // (j >= 128) and the first wave-local step after one do -- 18 barriers instead of 66 for 2048 keys.
+    bool crossed = false;                                        // the previous step crossed waves
     for (int k = 2; k <= NP2; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
+            const bool cross = j >= 128;
+            if (cross || crossed) __syncthreads();
+            else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             for (int t = tid; t < NP2 / 2; t += T) {
                 int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
                 int l = i | j;
@@ -131,9 +138,10 @@ __global__ __launch_bounds__(T) void k_nms_sort_small(const float4 *__restrict__
                 bool asc = (i & k) == 0;
                 if ((a > b) == asc) { keys[i] = b; keys[l] = a; }
             }
-            __syncthreads();
+            crossed = cross;
         }
     }
+    __syncthreads();
     const int64_t o = (int64_t)img * Np;
     for (int p = tid; p < (int)Np; p += T)
         gather_sorted(boxes, p < NP2 ? keys[p] : 0, p < n, o + p, x1, y1, x2, y2, area, order);
@@ -336,17 +344,14 @@ __device__ __forceinline__ u64 readlane64(u64 v, int l)
     return ((u64)hi << 32) | lo;
 }
 
+// the serial chain over 64-row blocks straight from the dense mask: the body of k_nms_reduce, also what
+// k_nms_resolve_small falls back to (every pointer already at the image)
 template <int T, int WPT>
-__global__ __launch_bounds__(T) void k_nms_reduce(const u64 *__restrict__ mask, const int32_t *__restrict__ order,
-                                                  const int32_t *__restrict__ counts, int64_t nmax, int64_t Np, int64_t W,
-                                                  int quirk, int64_t *__restrict__ keep, int32_t *__restrict__ keep_count)
+__device__ __forceinline__ void nms_reduce_serial(const u64 *__restrict__ mask, const int32_t *__restrict__ order, int n, int64_t W,
+                                                  int quirk, int64_t *__restrict__ keep, int32_t *__restrict__ keep_count_img)
 {
     __shared__ u64 s_remv, s_kept, s_curb;
-    const int img = blockIdx.x, tid = threadIdx.x;
-    const int n = counts ? counts[img] : (int)nmax;
-    mask += (int64_t)img * Np * W;
-    order += (int64_t)img * Np;
-    keep += (int64_t)img * nmax;
+    const int tid = threadIdx.x;
 
     u64 remv[WPT], prev[WPT];
 #pragma unroll
@@ -426,7 +431,161 @@ __global__ __launch_bounds__(T) void k_nms_reduce(const u64 *__restrict__ mask, 
         surv = __syncthreads_or(surv);
         if (!surv) total -= 1;
     }
-    if (tid == 0) keep_count[img] = total;
+    if (tid == 0) *keep_count_img = total;
+}
+
+template <int T, int WPT>
+__global__ __launch_bounds__(T) void k_nms_reduce(const u64 *__restrict__ mask, const int32_t *__restrict__ order,
+                                                  const int32_t *__restrict__ counts, int64_t nmax, int64_t Np, int64_t W,
+                                                  int quirk, int64_t *__restrict__ keep, int32_t *__restrict__ keep_count)
+{
+    const int img = blockIdx.x;
+    const int n = counts ? counts[img] : (int)nmax;
+    nms_reduce_serial<T, WPT>(mask + (int64_t)img * Np * W, order + (int64_t)img * Np, n, W, quirk, keep + (int64_t)img * nmax,
+                              keep_count + img);
+}
+
+// ---------------------------------------------------------------- fixed-point keep list from the dense mask (8 <= W <= 64)
+// Images of 449 .. 4096 boxes (one 2000-proposal image, config 1; the 256 x 2000 batch, config 3).  The serial chain over
+// 64-row blocks paid a compaction launch (k_nms_csr_build_small, 13 us) and about 0.7 us per block (25-50 us for one
+// 2000-box image); here ONE launch gathers the non-zero mask words of the image into LDS -- (row << 16 | word, bits), found
+// through the row summaries, every word's load in flight at once -- and then decides the boxes in ROUNDS like
+// k_nms_resolve_fp (see there), all entries in registers, the four bit sets in LDS: a round is two barriers.  More entries
+// than the LDS holds, or no end after max_rounds, and the serial chain over the dense mask finishes the image instead.
+#define RS_CAP 8192
+#define RS_PER (RS_CAP / 1024)
+__global__ __launch_bounds__(1024) void k_nms_resolve_small(const u64 *__restrict__ mask, const u64 *__restrict__ rsum,
+                                                            const int32_t *__restrict__ order, const int32_t *__restrict__ counts,
+                                                            int64_t nmax, int64_t Np, int64_t W, int max_rounds, int quirk,
+                                                            int64_t *__restrict__ keep, int32_t *__restrict__ keep_count)
+{
+    __shared__ u32 e_key[RS_CAP];                                // (row << 16 | word) of the non-zero words, in any order
+    __shared__ u64 K[64], R[64], R2[64], Bk[64];
+    __shared__ int s_cnt, s_last, s_off[64];
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = counts ? counts[img] : (int)nmax;
+    const int nb = (n + 63) >> 6;
+    mask += (int64_t)img * Np * W;
+    rsum += (int64_t)img * Np;                                    // one summary word per row (W <= 64)
+    order += (int64_t)img * Np;
+    keep += (int64_t)img * nmax;
+    u64 valid = 0;
+    if (tid < 64) {
+        const int64_t vb = (int64_t)tid * 64;
+        valid = (vb >= n) ? 0ull : ((n - vb >= 64) ? ~0ull : ((1ull << (n - vb)) - 1ull));
+        K[tid] = 0ull; R[tid] = 0ull; R2[tid] = 0ull; Bk[tid] = 0ull;
+    }
+    if (tid == 0) { s_cnt = 0; s_last = -1; }
+    // the `order` of the boxes this lane may have to write at the end (words wave, wave + 16, ...): fetched now
+    int ord[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int w = wave + 16 * u; ord[u] = (w < nb) ? order[w * 64 + lane] : 0; }
+    u64 bits[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int row = tid + 1024 * k;
+        bits[k] = (row < n) ? rsum[row] : 0ull;
+    }
+    __syncthreads();
+    bool over = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int row = tid + 1024 * k;
+        u64 b = (row < n) ? (bits[k] & ~((1ull << (row >> 6)) - 1ull)) : 0ull;     // words left of the diagonal were never written
+        const int c = __builtin_popcountll(b);
+        int at = c ? atomicAdd(&s_cnt, c) : 0;
+        while (b) {
+            const int w = __builtin_ctzll(b);
+            b &= b - 1;
+            if (at < RS_CAP) e_key[at] = ((u32)row << 16) | (u32)w;
+            ++at;
+        }
+    }
+    __syncthreads();
+    const int E = s_cnt;
+    over = E > RS_CAP;
+    u32 key[RS_PER];
+    u64 val[RS_PER];
+    u32 alive = 0;
+    if (!over) {
+#pragma unroll
+        for (int q = 0; q < RS_PER; ++q) {                        // every mask word of the image that matters, all loads together
+            const int e = tid + 1024 * q;
+            key[q] = e < E ? e_key[e] : 0u;
+            val[q] = e < E ? mask[(int64_t)(key[q] >> 16) * W + (key[q] & 0xffffu)] : 0ull;
+            if (e < E) alive |= 1u << q;
+        }
+    }
+    int rounds = 0;
+    bool bail = over;
+    if (!over) {
+        // round 0: boxes nothing suppresses are kept
+#pragma unroll
+        for (int q = 0; q < RS_PER; ++q)
+            if ((alive >> q) & 1u) atomicOr((unsigned long long *)&Bk[key[q] & 0xffffu], (unsigned long long)val[q]);
+        __syncthreads();
+        if (tid < 64) { K[tid] = valid & ~Bk[tid]; Bk[tid] = 0ull; }
+        for (;;) {
+            if (!__syncthreads_or(alive != 0u)) break;
+            if (rounds >= max_rounds) { bail = true; break; }
+#pragma unroll
+            for (int q = 0; q < RS_PER; ++q) {
+                if (!((alive >> q) & 1u)) continue;
+                const u32 row = key[q] >> 16, w = key[q] & 0xffffu;
+                const u64 rb = 1ull << (row & 63);
+                if (K[row >> 6] & rb) {
+                    const u64 old = atomicOr((unsigned long long *)&R[w], (unsigned long long)val[q]);
+                    if (old & val[q]) atomicOr((unsigned long long *)&R2[w], (unsigned long long)(old & val[q]));
+                    alive &= ~(1u << q);
+                } else if (R[row >> 6] & rb) {
+                    alive &= ~(1u << q);
+                } else {
+                    atomicOr((unsigned long long *)&Bk[w], (unsigned long long)val[q]);
+                }
+            }
+            __syncthreads();
+            if (tid < 64) { K[tid] |= valid & ~(K[tid] | R[tid] | Bk[tid]); Bk[tid] = 0ull; }
+            ++rounds;
+        }
+    }
+    if (bail) {                                                  // uniform
+        __syncthreads();
+        nms_reduce_serial<1024, 1>(mask, order, n, W, quirk, keep, keep_count + img);
+        return;
+    }
+    // ---- the kept set is final: count, quirk, keep list in rank order
+    const u64 kw = (tid < 64) ? K[tid] : 0ull;
+    const int mine = __builtin_popcountll(kw);
+    int incl = mine;
+    if (wave == 0) {
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
+        s_off[lane] = incl - mine;
+        if (kw) atomicMax(&s_last, tid * 64 + 63 - __builtin_clzll(kw));
+        if (lane == 63) s_cnt = incl;
+    }
+    __syncthreads();
+    const int total = s_cnt, km = s_last;
+    int drop = 0;
+    if (quirk && total > 0) {                                    // uniform
+        // yolo.py:196 `while ids_sorted.numel()>1`: the last kept box goes iff none of its own targets had only it as kept
+        // suppressor (every other lower-ranked box was already removed by the kept boxes before it)
+#pragma unroll
+        for (int q = 0; q < RS_PER; ++q)
+            if ((int)(key[q] >> 16) == km && tid + 1024 * q < E) atomicOr((unsigned long long *)&Bk[key[q] & 0xffffu], (unsigned long long)val[q]);
+        __syncthreads();
+        drop = !__syncthreads_or(tid < 64 && (Bk[tid] & ~R2[tid]) != 0ull);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int w = wave + 16 * u;
+        if (w < nb) {
+            u64 k = K[w];
+            if (drop && w == (km >> 6)) k &= ~(1ull << (km & 63));
+            if ((k >> lane) & 1ull) keep[s_off[w] + __builtin_popcountll(k & ((1ull << lane) - 1ull))] = (int64_t)ord[u];
+        }
+    }
+    if (tid == 0) keep_count[img] = total - drop;
 }
 
 // ---------------------------------------------------------------- reduce for DENSE masks (8 <= W <= 1024, compact form overflowed)
@@ -1659,7 +1818,7 @@ extern "C" int dg_nms_phase_sort(const float *boxes, const float *scores, const 
     case 64: launch_sort_small<64>(w, boxes, scores, counts, batch, nmax, st); break;
     case 128: launch_sort_small<128>(w, boxes, scores, counts, batch, nmax, st); break;
     case 256: launch_sort_small<256>(w, boxes, scores, counts, batch, nmax, st); break;
-    case 512: launch_sort_small<512>(w, boxes, scores, counts, batch, nmax, st); break;
+case 512: launch_sort_small<512>(w, boxes, scores, counts, batch, nmax, st); break;
     case 1024: launch_sort_small<1024>(w, boxes, scores, counts, batch, nmax, st); break;
     case 2048: launch_sort_small<2048>(w, boxes, scores, counts, batch, nmax, st); break;
     case 4096: launch_sort_small<4096>(w, boxes, scores, counts, batch, nmax, st); break;
@@ -1758,8 +1917,16 @@ extern "C" int dg_nms_phase_reduce(const int32_t *counts, int64_t batch, int64_t
     else if (w.W <= 1024) {
         // compact the mask, then the LDS-fed reduce; an image whose entries do not fit falls to the summary-driven kernel
         // DG_NMS_FORCE_FALLBACK=1 (tests): no image "fits" the compact form, every one takes the dense-mask reduce
-        const bool force_fb = getenv("DG_NMS_FORCE_FALLBACK") && atoi(getenv("DG_NMS_FORCE_FALLBACK")) != 0;
+        const bool force_fb = getenv("DG_NMS_FORCE_FALLBACK") && atoi(getenv("DG_NMS_FORCE_FALLBACK")) == 1;
         const int64_t ecap_fit = force_fb ? (int64_t)-1 : w.ecap;
+        if (w.W <= 64 && !force_fb) {
+            // one launch: the non-zero mask words gathered into LDS and the boxes decided in rounds (k_nms_resolve_small)
+            const int fb = getenv("DG_NMS_FORCE_FALLBACK") ? atoi(getenv("DG_NMS_FORCE_FALLBACK")) : 0;   // 2: its serial chain
+            hipLaunchKernelGGL(k_nms_resolve_small, dim3((unsigned)batch), dim3(1024), 0, st, w.mask, w.rsum, w.order, counts, nmax,
+                               w.Np, w.W, fb == 2 ? 0 : nms_fp_rounds(), quirk_drop_last, keep, keep_count);
+            DG_CHECK_LAUNCH("k_nms_resolve_small");
+            return DG_OK;
+        }
         if (w.W <= 64) {
             hipLaunchKernelGGL(k_nms_csr_build_small, dim3((unsigned)batch, batch < 32 ? 8u : 1u), dim3(1024), 0, st, w.mask, w.rsum, counts, nmax, w.Np, w.W,
                                ecap_fit, w.ecap, w.boff, w.cflag, w.ekey, w.eval);
