@@ -221,6 +221,17 @@ int dg_kmeans_finish(const int64_t *part, int64_t k, float *cent, int64_t *acc_o
 int dg_kmeans_iou_run(const float *wh, int64_t n, float *cent, int64_t k, uint8_t *labels, int64_t *acc,
                       int64_t *history, int64_t slot0, int64_t iters, void *ws, size_t ws_bytes, dg_stream_t s);
 int dg_kmeans_labels_i32(const uint8_t *labels, int64_t n, int32_t *out, dg_stream_t s);
+/* The PREPARED fit (NO COUNTERPART IN THE REFERENCE, like the 1-IoU k-means itself): dg_kmeans_prepare groups the boxes once
+ * by a cell of a log-spaced (w, h) grid (32 cells per octave over [2^-5, 1), everything else in catch-all cells) into the
+ * workspace, in pieces of at most 256 boxes with their fixed-point sums; dg_kmeans_iou_run_prepared then gives exactly
+ * what dg_kmeans_iou_run gives (cent, labels, acc, history: bit for bit) but decides whole pieces at once wherever the
+ * cell's bounds on the IoUs leave no doubt about the label, and walks only the other pieces box by box.  The workspace is
+ * bound to the CONTENTS of wh and to the labels as they were at prepare time: prepare again when either changes behind the
+ * library's back (labels written by dg_kmeans_iou_run_prepared itself are tracked).  ws 256-byte aligned. */
+size_t dg_kmeans_prepared_workspace_bytes(int64_t n, int64_t k);
+int dg_kmeans_prepare(const float *wh, int64_t n, int64_t k, const uint8_t *labels, void *ws, size_t ws_bytes, dg_stream_t s);
+int dg_kmeans_iou_run_prepared(const float *wh, int64_t n, float *cent, int64_t k, uint8_t *labels, int64_t *acc,
+                               int64_t *history, int64_t slot0, int64_t iters, void *ws, size_t ws_bytes, dg_stream_t s);
 
 /* ---------------------------------------------------------------- the exchange step of the sharded k-means
  * NO COUNTERPART IN THE REFERENCE (its KMeans is single-process sklearn, clustering/cluster_prac.py:38-40).  One process per

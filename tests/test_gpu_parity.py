@@ -1039,6 +1039,44 @@ def test_kmeans_fixed_iterations_vs_oracle(va, oracle, iters):
     assert km.n_iter_ == iters and abs(km.inertia_ - inertia) < 1e-9
 
 
+@pytest.mark.parametrize("n,k,iters", [(300001, 5, None), (250000, 9, 12), (500000, 3, 7), (400000, 16, 5), (1000, 5, None)])
+def test_kmeans_prepared_fit_vs_oracle(va, oracle, n, k, iters, monkeypatch):
+    """The prepared fit (dg_kmeans_prepare + dg_kmeans_iou_run_prepared: boxes grouped by (w, h) cell once, whole pieces of a
+    cell labelled at once where the bounds on the IoUs leave no doubt, the rest box by box): centroids, labels, n_iter_ and
+    inertia bit for bit those of the oracle's Lloyd loop and of the box-by-box loop; boxes outside the grid (zero, NaN-free
+    negatives, tiny, larger than 1) sit in the catch-all cells and are always walked.  No reference counterpart (parity
+    unpinned: the 1-IoU k-means is build-defined, spec in oracle.c)."""
+    from vision_amd import cluster
+    wh = wl.anchor_wh(n % 97, n)
+    if n == 500000:
+        wh[::1000] = [3.0, 0.5]; wh[5] = [0.0, 0.2]; wh[7] = [1e-4, 1e-4]; wh[11] = [-0.3, 0.4]
+    x = torch.from_numpy(wh).cuda()
+    monkeypatch.setenv("DG_KMEANS_CELLS", "1")
+    a = cluster.kmean(k, 42).fit(x, fixed_iters=iters)
+    assert a._backend.cells is not None
+    monkeypatch.setenv("DG_KMEANS_CELLS", "0")
+    b = cluster.kmean(k, 42).fit(x, fixed_iters=iters)
+    assert b._backend.cells is None
+    cent, labels, n_iter, inertia = oracle.kmeans_fit(wh, k, 42, fixed_iters=iters) if iters else oracle.kmeans_fit(wh, k, 42)
+    for km in (a, b):
+        assert np.array_equal(km.cluster_centers_.view(np.uint32), cent.view(np.uint32))
+        assert np.array_equal(km.labels_, labels) and km.n_iter_ == n_iter and abs(km.inertia_ - inertia) < 1e-9
+    # a second chunk on the same prepared workspace continues the fit: history and centroids as the oracle's longer run
+    if iters:
+        monkeypatch.setenv("DG_KMEANS_CELLS", "1")
+        c = cluster.kmean(k, 42).fit(x, fixed_iters=iters)
+        c._run_iters(0, 3)
+        torch.cuda.synchronize()
+        cent2, labels2, _, _ = oracle.kmeans_fit(wh, k, 42, fixed_iters=iters + 3)
+        assert np.array_equal(c._backend.cent.cpu().numpy().view(np.uint32), cent2.view(np.uint32))
+        assert np.array_equal(c._backend.labels.cpu().numpy().astype(np.int32), labels2)
+        h_acc = np.zeros(3 * k + 2, np.int64); lab = np.full(n, 255, np.uint8); ce = oracle.kmeans_init(wh, k, 42)
+        hist = []
+        for _ in range(iters + 3):
+            acc = oracle.kmeans_step(wh, ce, lab); hist.append(int(acc[3 * k])); ce = oracle.kmeans_update(acc, ce)
+        assert list(c._backend.history_host(3)) == hist[iters:iters + 3]
+
+
 def test_kmeans_sharded_equals_single(va, oracle):
     """fake all-reduce: shards stepped one after another on one device, integer partial sums added."""
     from vision_amd import ops

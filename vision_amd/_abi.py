@@ -60,6 +60,9 @@ SIGNATURES = {
     "dg_kmeans_finish": (C.c_int, [_vp, _i64, _vp, _vp, _vp, _i64, _vp]),
     "dg_kmeans_iou_run": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _sz, _vp]),
     "dg_kmeans_labels_i32": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "dg_kmeans_prepared_workspace_bytes": (_sz, [_i64, _i64]),
+    "dg_kmeans_prepare": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _sz, _vp]),
+    "dg_kmeans_iou_run_prepared": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _sz, _vp]),
     "dg_comm_unique_id": (C.c_int, [_vp]),
     "dg_comm_init": (C.c_int, [C.POINTER(_vp), _vp, C.c_int, C.c_int]),
     "dg_comm_rank": (C.c_int, [_vp]),

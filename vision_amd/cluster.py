@@ -24,6 +24,7 @@ import torch.distributed as dist
 from . import _abi, ops
 
 _CHUNK = 8          # iterations launched between two host checks of the changed-count history
+_CELLS_MIN_BOXES = 200_000   # single-device fits of at least this many boxes take the prepared (cell) path
 
 
 class DgComm:
@@ -72,7 +73,7 @@ class DgComm:
 class _HipBackend:
     """Device side of the Lloyd loop: HIP kernels through the C ABI (the only backend the product has)."""
 
-    def prepare(self, X, init_centers, k, iters):
+    def prepare(self, X, init_centers, k, iters, cells=None):
         dev = _abi.device_of(X)
         lib = _abi.load()
         self.wh = _abi.to_dev(X, torch.float32, dev).reshape(-1, 2)
@@ -87,10 +88,28 @@ class _HipBackend:
         self.part = torch.zeros((3, lib.dg_kmeans_part_elems(k)), dtype=torch.int64, device=dev)
         self.cur = None               # index of the buffer the last launch added into
         self._bound = None
+        # single device, many boxes: the prepared fit (boxes grouped by (w, h) cell once, iterations over pieces of cells;
+        # same bits, include/detgeom.h).  DG_KMEANS_CELLS=0 keeps the box-by-box loop, =1 forces the prepared one.
+        self.cells = None
+        mode = os.environ.get("DG_KMEANS_CELLS", "")
+        n = self.wh.shape[0]
+        if cells is not False and mode != "0" and n >= 1 and (mode == "1" or cells is True or n >= _CELLS_MIN_BOXES):
+            nb = lib.dg_kmeans_prepared_workspace_bytes(n, k)
+            self.cells = (torch.empty(nb, dtype=torch.uint8, device=dev), nb)
+            with torch.cuda.device(dev):
+                _abi.check(lib.dg_kmeans_prepare(_abi.ptr(self.wh), n, k, _abi.ptr(self.labels), _abi.ptr(self.cells[0]), nb,
+                                                 _abi.stream_ptr(dev)))
 
     def run_local(self, slot0, iters):
         """single device: `iters` launches issued by one C call (dg_kmeans_iou_run)"""
         dev = self.wh.device
+        if self.cells is not None:
+            with torch.cuda.device(dev):
+                _abi.check(_abi.load().dg_kmeans_iou_run_prepared(_abi.ptr(self.wh), self.wh.shape[0], _abi.ptr(self.cent),
+                                                                  self.cent.shape[0], _abi.ptr(self.labels), _abi.ptr(self.acc),
+                                                                  _abi.ptr(self.history), slot0, iters, _abi.ptr(self.cells[0]),
+                                                                  self.cells[1], _abi.stream_ptr(dev)))
+            return
         with torch.cuda.device(dev):
             _abi.check(_abi.load().dg_kmeans_iou_run(_abi.ptr(self.wh), self.wh.shape[0], _abi.ptr(self.cent), self.cent.shape[0],
                                                      _abi.ptr(self.labels), _abi.ptr(self.acc), _abi.ptr(self.history), slot0, iters,
@@ -225,7 +244,8 @@ class kmean:
         iters = fixed_iters if fixed_iters is not None else self.max_iter
         be = self._backend
         self._graphs = {}
-        be.prepare(X, init_centers, k, min(iters, _CHUNK) if fixed_iters is None else iters)
+        be.prepare(X, init_centers, k, min(iters, _CHUNK) if fixed_iters is None else iters,
+                   cells=False if self._is_sharded() else None)
         done, n_iter = 0, 0
         while done < iters:
             chunk = min(_CHUNK if fixed_iters is None else iters, iters - done)

@@ -669,3 +669,473 @@ extern "C" int dg_kmeans_labels_i32(const uint8_t *labels, int64_t n, int32_t *o
     DG_CHECK_LAUNCH("k_labels_widen");
     return DG_OK;
 }
+
+// ================================================================ the prepared fit: Lloyd iterations over CELLS of boxes
+// NO COUNTERPART IN THE REFERENCE (like the whole 1-IoU k-means; spec: oracle/oracle.c orc_kmeans_*).
+// The label of a box is a function of (w, h) and the centroids alone, so boxes that lie close together in (w, h) almost
+// always share it.  dg_kmeans_prepare groups the boxes ONCE per fit by a cell of a log-spaced grid -- the float's exponent
+// and its top five mantissa bits, per coordinate: 32 cells per octave over [2^-5, 1), 162 x 162 cells with the catch-all
+// cells for everything else -- with a counting sort (per-workgroup LDS histograms: device-scope atomics are far too slow
+// on this part), cuts every cell into PIECES of at most 256 boxes and sums each piece's fixed-point w and h.  An iteration
+// (k_kc_iter) then looks at pieces: from the cell's bounds it bounds every centroid's IoU over the whole cell from below
+// and above (IoU = I / (a + A - I) grows with the overlap I and falls with the box area a); if one centroid's lower bound
+// beats every other's upper bound by more than 2^-20 -- an order of magnitude more than the rounding of the fp32 distances
+// the specification compares -- every box of the piece gets that label and the piece's precomputed sums are added as
+// they are: integer sums, so the totals are bit for bit those of a pass over the boxes.  Only the pieces of ambiguous
+// cells (and of the catch-all cells) are walked box by box with the exact assignment of k_kmeans_step.  On config 4 about a
+// fifth of the boxes is walked per iteration; the rest costs one table-free decision per 256 boxes.
+// Labels live in sorted order inside the workspace (per piece while it is decided as a whole, per box otherwise), which
+// is all the `changed` count needs; the caller's `labels` array, the inertia and acc come from one ordinary
+// k_kmeans_step at the last iteration of a run (same centroids, same sums), so nothing is ever un-sorted.
+#define KC_N 162
+#define KC_NC (KC_N * KC_N)
+#define KC_G 256
+#define KC_PIECE 256
+#define KC_WG_PIECES 64
+#define KC_MAGIC 0x4b43656c6c733033ull
+struct KcHdr {
+    unsigned long long magic;
+    const void *wh;
+    long long n;
+    int k, npieces;
+    long long pad[4];
+};
+struct KcWs {
+    long long *part[4];
+    KcHdr *hdr;
+    float2 *swh;
+    uint8_t *slab, *plab;
+    int *counts, *tot, *cell_start, *piece_first, *pcell, *pstart, *pcnt;
+    long long *psum;
+    float4 *pbox;
+    long long pmax;
+    size_t total;
+};
+static KcWs kc_layout(int64_t n, int64_t k, void *base)
+{
+    KcWs w;
+    char *p = (char *)base;
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *r = p + off; off += (bytes + 255) & ~(size_t)255; return r; };
+    const size_t pe = dg_kmeans_part_elems(k);
+    for (int i = 0; i < 4; ++i) w.part[i] = (long long *)take(pe * 8);
+    w.hdr = (KcHdr *)take(sizeof(KcHdr));
+    w.swh = (float2 *)take((size_t)n * 8);
+    w.slab = (uint8_t *)take((size_t)n);
+    w.pmax = n / KC_PIECE + KC_NC + 1;
+    w.plab = (uint8_t *)take((size_t)w.pmax);
+    w.counts = (int *)take((size_t)KC_G * KC_NC * 4);
+    w.tot = (int *)take((size_t)KC_NC * 4);
+    w.cell_start = (int *)take((size_t)(KC_NC + 1) * 4);
+    w.piece_first = (int *)take((size_t)(KC_NC + 1) * 4);
+    w.pcell = (int *)take((size_t)w.pmax * 4);
+    w.pstart = (int *)take((size_t)w.pmax * 4);
+    w.pcnt = (int *)take((size_t)w.pmax * 4);
+    w.psum = (long long *)take((size_t)w.pmax * 16);
+    w.pbox = (float4 *)take((size_t)w.pmax * 16);
+    w.total = off;
+    return w;
+}
+
+__device__ __forceinline__ int kc_cell1(float x)
+{
+    const unsigned b = __float_as_uint(x);
+    if (!(x > 0.0f) || b >= 0x7f800000u) return 0;               // zero, negative, NaN, inf: the catch-all cell
+    const int e = (int)(b >> 18) - 3904 + 1;                     // 3904 = (127 - 5) << 5: 2^-5
+    return e < 1 ? 0 : (e > KC_N - 1 ? KC_N - 1 : e);
+}
+__device__ __forceinline__ int kc_cell(float2 b) { return kc_cell1(b.y) * KC_N + kc_cell1(b.x); }
+__device__ __forceinline__ float kc_edge(int idx) { return __uint_as_float((unsigned)(idx - 1 + 3904) << 18); }   // lower edge of cell idx in 1..160; idx + 1: upper
+
+// per-workgroup histogram of the cells of a contiguous slice of the boxes (LDS atomics), written wg-major
+__global__ __launch_bounds__(1024) void k_kc_hist(const float2 *__restrict__ wh, long long n, int *__restrict__ counts)
+{
+    extern __shared__ int kc_h[];
+    const int tid = threadIdx.x, g = blockIdx.x;
+    for (int c = tid; c < KC_NC; c += 1024) kc_h[c] = 0;
+    __syncthreads();
+    const long long S = (n + KC_G - 1) / KC_G, lo = g * S, hi = lo + S < n ? lo + S : n;
+    for (long long i = lo + tid; i < hi; i += 1024) atomicAdd(&kc_h[kc_cell(wh[i])], 1);
+    __syncthreads();
+    for (int c = tid; c < KC_NC; c += 1024) counts[(size_t)g * KC_NC + c] = kc_h[c];
+}
+// per cell: the slices' counts become their exclusive prefix over the slices, the total goes to tot[]
+__global__ __launch_bounds__(256) void k_kc_colscan(int *__restrict__ counts, int *__restrict__ tot)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= KC_NC) return;
+    int run = 0;
+    for (int g = 0; g < KC_G; ++g) { const int v = counts[(size_t)g * KC_NC + c]; counts[(size_t)g * KC_NC + c] = run; run += v; }
+    tot[c] = run;
+}
+// one workgroup: where every cell starts in the sorted order, and its first piece
+__global__ __launch_bounds__(1024) void k_kc_scan(const int *__restrict__ tot, int *__restrict__ cell_start, int *__restrict__ piece_first,
+                                                  KcHdr *__restrict__ hdr, const void *wh, long long n, int k)
+{
+    __shared__ int s_a[1024], s_b[1024];
+    const int tid = threadIdx.x;
+    constexpr int PER = (KC_NC + 1023) / 1024;
+    int a = 0, b = 0;
+    for (int j = 0; j < PER; ++j) { const int c = tid * PER + j; if (c < KC_NC) { a += tot[c]; b += (tot[c] + KC_PIECE - 1) / KC_PIECE; } }
+    s_a[tid] = a; s_b[tid] = b;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+        const int va = tid >= o ? s_a[tid - o] : 0, vb = tid >= o ? s_b[tid - o] : 0;
+        __syncthreads();
+        s_a[tid] += va; s_b[tid] += vb;
+        __syncthreads();
+    }
+    int ra = s_a[tid] - a, rb = s_b[tid] - b;
+    for (int j = 0; j < PER; ++j) {
+        const int c = tid * PER + j;
+        if (c < KC_NC) { cell_start[c] = ra; piece_first[c] = rb; ra += tot[c]; rb += (tot[c] + KC_PIECE - 1) / KC_PIECE; }
+    }
+    if (tid == 1023) {
+        cell_start[KC_NC] = s_a[1023]; piece_first[KC_NC] = s_b[1023];
+        hdr->magic = KC_MAGIC; hdr->wh = wh; hdr->n = n; hdr->k = k; hdr->npieces = s_b[1023];
+    }
+}
+__global__ __launch_bounds__(256) void k_kc_pieces(const int *__restrict__ tot, const int *__restrict__ cell_start,
+                                                   const int *__restrict__ piece_first, int *__restrict__ pcell, int *__restrict__ pstart,
+                                                   int *__restrict__ pcnt, uint8_t *__restrict__ plab)
+{
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= KC_NC) return;
+    const int t = tot[c], s = cell_start[c], p0 = piece_first[c];
+    for (int j = 0; j * KC_PIECE < t; ++j) {
+        pcell[p0 + j] = c; pstart[p0 + j] = s + j * KC_PIECE; pcnt[p0 + j] = t - j * KC_PIECE < KC_PIECE ? t - j * KC_PIECE : KC_PIECE;
+        plab[p0 + j] = 255;                                       // labels per box (the caller's, copied into slab)
+    }
+}
+// boxes (and the caller's current labels) into cell order: the slice's cursors start where its prefix says
+__global__ __launch_bounds__(1024) void k_kc_scatter(const float2 *__restrict__ wh, const uint8_t *__restrict__ labels, long long n,
+                                                     const int *__restrict__ counts, const int *__restrict__ cell_start,
+                                                     float2 *__restrict__ swh, uint8_t *__restrict__ slab)
+{
+    extern __shared__ int kc_h[];
+    const int tid = threadIdx.x, g = blockIdx.x;
+    for (int c = tid; c < KC_NC; c += 1024) kc_h[c] = cell_start[c] + counts[(size_t)g * KC_NC + c];
+    __syncthreads();
+    const long long S = (n + KC_G - 1) / KC_G, lo = g * S, hi = lo + S < n ? lo + S : n;
+    for (long long i = lo + tid; i < hi; i += 1024) {
+        const float2 b = wh[i];
+        const int at = atomicAdd(&kc_h[kc_cell(b)], 1);
+        swh[at] = b;
+        slab[at] = labels[i];
+    }
+}
+// one wave per piece: its fixed-point sums of w and h (the values k_kmeans_step would add box by box)
+__global__ __launch_bounds__(256) void k_kc_piecesums(const float2 *__restrict__ swh, const int *__restrict__ pstart,
+                                                      const int *__restrict__ pcnt, const KcHdr *__restrict__ hdr,
+                                                      long long *__restrict__ psum, float4 *__restrict__ pbox)
+{
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (p >= hdr->npieces) return;
+    const int s = pstart[p], c = pcnt[p];
+    long long sw = 0, sh = 0;
+    float wlo = INFINITY, whi = -INFINITY, hlo = INFINITY, hhi = -INFINITY;
+    bool bad = false;
+    for (int j = lane; j < c; j += 64) {
+        const float2 b = swh[s + j];
+        sw += fx32(b.x); sh += fx32(b.y);
+        wlo = fminf(wlo, b.x); whi = fmaxf(whi, b.x); hlo = fminf(hlo, b.y); hhi = fmaxf(hhi, b.y);
+        bad |= !(b.x > 0.0f) || !(b.y > 0.0f) || !(b.x < KM_FAST_LIMIT) || !(b.y < KM_FAST_LIMIT);
+    }
+    sw = wave_sum_ll(sw); sh = wave_sum_ll(sh);
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        wlo = fminf(wlo, __shfl_xor(wlo, d, 64)); whi = fmaxf(whi, __shfl_xor(whi, d, 64));
+        hlo = fminf(hlo, __shfl_xor(hlo, d, 64)); hhi = fmaxf(hhi, __shfl_xor(hhi, d, 64));
+    }
+    bad = __ballot(bad) != 0ull;
+    if (lane == 0) {
+        psum[2 * (size_t)p] = sw; psum[2 * (size_t)p + 1] = sh;
+        // the piece's own bounding box in (w, h): what the decision bounds the IoUs over; a piece with a box that is not a
+        // positive finite number of moderate size is never decided as a whole (whi < wlo says so)
+        pbox[p] = bad ? make_float4(1.f, 0.f, 1.f, 0.f) : make_float4(wlo, whi, hlo, hhi);
+    }
+}
+
+// The decision for one piece: the label all its boxes get, or 255 (walk the boxes).  For a fixed centroid the IoU of a box
+// (w, h) rises with w up to the centroid's width and falls beyond it, whatever h is, and the same in h: over the piece's
+// bounding box its maximum sits at the point nearest the centroid and its minimum at one of the four corners.  Those five
+// values per centroid are evaluated in fp32 (a few 1e-7 off at most); one centroid's minimum must beat every other's
+// maximum by 4e-6 -- the fp32 distances the specification compares are then ordered the same way for every box of the
+// piece, with room to spare for their own rounding (2^-23) -- or the piece is walked.
+__device__ __forceinline__ float kc_iou(float w, float h, float cw, float ch)
+{
+    const float inter = fminf(w, cw) * fminf(h, ch);
+    return inter / ((w * h + cw * ch) - inter);
+}
+template <int KMAX, bool FULL>
+__device__ __forceinline__ int kc_decide(float4 bb, const float (&cw)[KMAX], const float (&ch)[KMAX], int k)
+{
+    const float wlo = bb.x, whi = bb.y, hlo = bb.z, hhi = bb.w;
+    if (!(wlo <= whi)) return 255;
+    float best_lo = -1.0f, top_hi = -1.0f, second_hi = -1.0f;
+    int best = 0, top = 0;
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c) {
+        if (FULL || c < k) {
+            const float qhi = kc_iou(fminf(fmaxf(cw[c], wlo), whi), fminf(fmaxf(ch[c], hlo), hhi), cw[c], ch[c]);
+            const float qlo = fminf(fminf(kc_iou(wlo, hlo, cw[c], ch[c]), kc_iou(whi, hlo, cw[c], ch[c])),
+                                    fminf(kc_iou(wlo, hhi, cw[c], ch[c]), kc_iou(whi, hhi, cw[c], ch[c])));
+            if (qlo > best_lo) { best_lo = qlo; best = c; }
+            if (qhi > top_hi) { second_hi = top_hi; top_hi = qhi; top = c; }
+            else if (qhi > second_hi) second_hi = qhi;
+        }
+    }
+    const float rival = (top == best) ? second_hi : top_hi;       // the largest maximum among the OTHER centroids
+    return (best_lo > rival + 4e-6f) ? best : 255;
+}
+
+template <int KMAX, bool FULL>
+__global__ __launch_bounds__(KM_BLOCK) void k_kc_iter(const KcHdr *__restrict__ hdr, const float2 *__restrict__ swh,
+                                                      uint8_t *__restrict__ slab, uint8_t *__restrict__ plab,
+                                                      const int *__restrict__ pcell, const int *__restrict__ pstart,
+                                                      const int *__restrict__ pcnt, const long long *__restrict__ psum,
+                                                      const float4 *__restrict__ pbox, float *cent, int k, const long long *part_prev, long long *part_out, long long *part_zero,
+                                                      long long *__restrict__ history, int64_t slot, int write_cent, int pmax)
+{
+    constexpr int COLS = 3 * KMAX + 2;
+    __shared__ unsigned long long sacc_all[KMAX * 2 * KM_BLOCK];
+    __shared__ unsigned scnt_all[KMAX * KM_BLOCK];
+    __shared__ float2 scent[16];
+    __shared__ long long s_prev[3 * 16 + 2];
+    __shared__ int s_queue[KC_WG_PIECES], s_qstart[KC_WG_PIECES], s_qcnt[KC_WG_PIECES], s_qn;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pstride = km_stride(k), cols = 3 * k + 2;
+    const int P = pmax;                                          // slots past the last piece hold pcnt == 0
+    // 64 pieces per workgroup, decided by its first wave (one per lane), interleaved over the grid so that every workgroup
+    // gets pieces from all over the (w, h) plane; the pieces that have to be walked are then shared by its four waves
+    const int p = (tid < KC_WG_PIECES) ? tid * (int)gridDim.x + (int)blockIdx.x : P;
+    int pst = 0, pc = 0;
+    long long ps0 = 0, ps1 = 0;
+    unsigned prevl = 255;
+    float4 bb = make_float4(1.f, 0.f, 1.f, 0.f);
+    if (p < P) { bb = pbox[p]; pst = pstart[p]; pc = pcnt[p]; ps0 = psum[2 * (size_t)p]; ps1 = psum[2 * (size_t)p + 1]; prevl = plab[p]; }
+    const bool valid = pc > 0;
+    long long pv[KM_REPL];
+#pragma unroll
+    for (int r = 0; r < KM_REPL; ++r) pv[r] = (part_prev && tid < cols) ? part_prev[r * pstride + tid] : 0;
+    float2 c_old = make_float2(0.f, 0.f);
+    if (tid < k) c_old = make_float2(cent[2 * tid], cent[2 * tid + 1]);
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c) {
+        sacc_all[(c * 2 + 0) * KM_BLOCK + tid] = 0;
+        sacc_all[(c * 2 + 1) * KM_BLOCK + tid] = 0;
+        scnt_all[c * KM_BLOCK + tid] = 0;
+    }
+    if (tid == 0) s_qn = 0;
+    if (tid < cols) {
+        long long t = 0;
+#pragma unroll
+        for (int r = 0; r < KM_REPL; ++r) t += pv[r];
+        s_prev[tid] = t;
+    }
+    __syncthreads();
+    if (tid < 16) {
+        float2 c = c_old;
+        if (part_prev && tid < k) {
+            const long long cnt = s_prev[2 * k + tid];
+            if (cnt > 0) { c.x = km_centroid(s_prev[tid], cnt); c.y = km_centroid(s_prev[k + tid], cnt); }
+        }
+        scent[tid] = c;
+        if (write_cent && blockIdx.x == 0 && part_prev && tid < k) { cent[2 * tid] = c.x; cent[2 * tid + 1] = c.y; }   // idempotent, see k_kmeans_step
+    }
+    if (blockIdx.x == 0) {
+        if (part_zero)
+            for (int z = tid; z < KM_REPL * pstride; z += KM_BLOCK) part_zero[z] = 0;
+        if (part_prev && history && tid == 0) history[slot] = s_prev[3 * k];
+    }
+    __syncthreads();
+    float cw[KMAX], ch[KMAX];
+    bool cent_ok = true;
+#pragma unroll
+    for (int c = 0; c < KMAX; ++c) {
+        cw[c] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(scent[c < 16 ? c : 0].x)));
+        ch[c] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(scent[c < 16 ? c : 0].y)));
+        if (FULL || c < k) cent_ok = cent_ok && (cw[c] > 0.0f) && (ch[c] > 0.0f) && (cw[c] * ch[c] < 0x1p60f);
+    }
+    const unsigned gap_min = cent_ok ? KM_GAP_MIN : 0xffffffffu;
+    unsigned long long *sacc = sacc_all + tid;
+    unsigned *scnt = scnt_all + tid;
+    unsigned long long inertia = 0;
+    int changed = 0;
+    // ---- pieces decided as a whole: the piece's sums go in as they are (biased like the box-by-box sums: KM_MAGIC per box)
+    if (valid) {
+        const int L = cent_ok ? kc_decide<KMAX, FULL>(bb, cw, ch, k) : 255;
+        if (L != 255) {
+            atomicAdd(&sacc[(L * 2 + 0) * KM_BLOCK], (unsigned long long)ps0 + (unsigned long long)pc * KM_MAGIC);
+            atomicAdd(&sacc[(L * 2 + 1) * KM_BLOCK], (unsigned long long)ps1 + (unsigned long long)pc * KM_MAGIC);
+            atomicAdd(&scnt[L * KM_BLOCK], (unsigned)pc);
+            if (prevl == 255u) {                                   // its boxes were labelled one by one last time
+                int ch_ = 0;
+                for (int j = 0; j < pc; ++j) ch_ += slab[pst + j] != (uint8_t)L;
+                changed += ch_;
+            } else if (prevl != (unsigned)L) {
+                changed += pc;
+            }
+            plab[p] = (uint8_t)L;
+        } else {
+            const int at = atomicAdd(&s_qn, 1);                    // this thread's piece is walked below
+            s_queue[at] = tid; s_qstart[at] = pst; s_qcnt[at] = pc | ((int)prevl << 16);
+        }
+    }
+    __syncthreads();
+    // ---- the other pieces box by box, one wave per piece, four boxes per lane: k_kmeans_step's exact assignment
+    const int qn = s_qn;
+    for (int qi = wave; qi < qn; qi += KM_BLOCK / 64) {
+        const int owner = s_queue[qi];
+        const int qp = owner * (int)gridDim.x + (int)blockIdx.x;
+        const int qs = s_qstart[qi], qc = s_qcnt[qi] & 0xffff;
+        const unsigned ql = (unsigned)s_qcnt[qi] >> 16;
+#pragma unroll
+        for (int j = 0; j < KC_PIECE / 64; ++j) {
+            const int o = lane + 64 * j;
+            if (o < qc) {
+                const float2 b = swh[qs + o];
+                const unsigned old = (ql == 255u) ? (unsigned)slab[qs + o] : ql;
+                int best;
+                float bd = 0.f;
+                if (!(km_filter<KMAX, FULL>(b.x, b.y, cw, ch, k, gap_min, best) && (fabsf(b.x) + fabsf(b.y)) < KM_FAST_LIMIT))
+                    best = km_assign<KMAX, FULL>(b.x, b.y, cw, ch, k, bd);
+                if ((fabsf(b.x) + fabsf(b.y)) < KM_FAST_LIMIT) km_accum<true, false>(b.x, b.y, 0.f, best, sacc, scnt, inertia, changed, slab + qs + o, old);
+                else km_accum<false, false>(b.x, b.y, 0.f, best, sacc, scnt, inertia, changed, slab + qs + o, old);
+            }
+        }
+        if (lane == 0) plab[qp] = 255;
+    }
+    // ---- block reduction and the replica row: as k_kmeans_step
+    __shared__ unsigned s_changed[KM_BLOCK];
+    __shared__ unsigned long long s_cpart[COLS][16];
+    s_changed[tid] = (unsigned)changed;
+    __syncthreads();
+    {
+        const int sub = tid & 15;
+        for (int col = tid >> 4; col < COLS; col += KM_BLOCK / 16) {
+            unsigned long long t = 0;
+            if (col < 2 * KMAX) {
+                const unsigned long long *src = sacc_all + ((col % KMAX) * 2 + col / KMAX) * KM_BLOCK;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) t += src[j * 16 + sub];
+            } else if (col < 3 * KMAX) {
+                const unsigned *src = scnt_all + (col - 2 * KMAX) * KM_BLOCK;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) t += src[j * 16 + sub];
+            } else if (col == 3 * KMAX) {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) t += s_changed[j * 16 + sub];
+            }
+            s_cpart[col][sub] = t;
+        }
+    }
+    __syncthreads();
+    if (tid < COLS) {
+        unsigned long long v = 0;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v += s_cpart[tid][j];
+        const int grp = tid / KMAX, c = tid - grp * KMAX;
+        if (grp < 2) {
+            unsigned long long cnt = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) cnt += s_cpart[2 * KMAX + c][j];
+            v -= cnt * KM_MAGIC;
+        }
+        const int col = (grp < 3) ? (c < k ? grp * k + c : -1) : 3 * k + c;
+        if (col >= 0 && v != 0)
+            atomicAdd(reinterpret_cast<unsigned long long *>(part_out) + (blockIdx.x % KM_REPL) * pstride + col, v);
+    }
+}
+
+// history[slot] and acc[3k] <- the changed count of the cell pass (the box-order pass that produced acc compares with the
+// caller's label array, which the cell iterations do not keep up to date)
+__global__ void k_kc_changed(const long long *__restrict__ part, int k, long long *__restrict__ acc, long long *__restrict__ history,
+                             int64_t slot)
+{
+    long long t = 0;
+    for (int r = 0; r < KM_REPL; ++r) t += part[r * km_stride(k) + 3 * k];
+    if (acc) acc[3 * k] = t;
+    if (history) history[slot] = t;
+}
+
+extern "C" size_t dg_kmeans_prepared_workspace_bytes(int64_t n, int64_t k)
+{
+    if (n < 0 || k <= 0 || k > 16 || n >= (1ll << 31)) return 0;
+    return kc_layout(n, k, nullptr).total;
+}
+
+extern "C" int dg_kmeans_prepare(const float *wh, int64_t n, int64_t k, const uint8_t *labels, void *ws, size_t ws_bytes, dg_stream_t s)
+{
+    DG_REQUIRE(n >= 1 && n < (1ll << 31) && k >= 1 && k <= 16, "kmeans_prepare: need 1 <= n < 2^31 and 1 <= k <= 16");
+    DG_REQUIRE(wh && labels && (((uintptr_t)wh) & 7) == 0, "kmeans_prepare: null or misaligned pointer");
+    DG_REQUIRE(ws && (((uintptr_t)ws) & 255) == 0, "kmeans_prepare: workspace null or not 256-byte aligned");
+    if (ws_bytes < dg_kmeans_prepared_workspace_bytes(n, k)) { dg_set_error("kmeans_prepare: workspace too small"); return DG_ENOMEM; }
+    hipStream_t st = (hipStream_t)s;
+    KcWs w = kc_layout(n, k, ws);
+    const size_t lds = (size_t)KC_NC * 4;
+    if (hipFuncSetAttribute((const void *)k_kc_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_kc_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        dg_set_error("kmeans_prepare: cannot raise the LDS limit"); return DG_EHIP;
+    }
+    if (hipMemsetAsync(w.pcnt, 0, (size_t)w.pmax * 4, st) != hipSuccess) { dg_set_error("kmeans_prepare: memset failed"); return DG_EHIP; }
+    hipLaunchKernelGGL(k_kc_hist, dim3(KC_G), dim3(1024), lds, st, (const float2 *)wh, (long long)n, w.counts);
+    hipLaunchKernelGGL(k_kc_colscan, dim3((KC_NC + 255) / 256), dim3(256), 0, st, w.counts, w.tot);
+    hipLaunchKernelGGL(k_kc_scan, dim3(1), dim3(1024), 0, st, w.tot, w.cell_start, w.piece_first, w.hdr, (const void *)wh, (long long)n, (int)k);
+    hipLaunchKernelGGL(k_kc_pieces, dim3((KC_NC + 255) / 256), dim3(256), 0, st, w.tot, w.cell_start, w.piece_first, w.pcell, w.pstart, w.pcnt, w.plab);
+    hipLaunchKernelGGL(k_kc_scatter, dim3(KC_G), dim3(1024), lds, st, (const float2 *)wh, labels, (long long)n, w.counts, w.cell_start, w.swh, w.slab);
+    hipLaunchKernelGGL(k_kc_piecesums, dim3((unsigned)((w.pmax + 3) / 4)), dim3(256), 0, st, w.swh, w.pstart, w.pcnt, w.hdr, w.psum, w.pbox);
+    DG_CHECK_LAUNCH("kmeans_prepare");
+    return DG_OK;
+}
+
+static int kc_launch(const KcWs &w, float *cent, int64_t k, const long long *prev, long long *out, long long *zero, int64_t *history,
+                     int64_t slot, int write_cent, hipStream_t st)
+{
+    const unsigned grid = (unsigned)((w.pmax + KC_WG_PIECES - 1) / KC_WG_PIECES);
+#define KC_LAUNCH(KM, FULL)                                                                                                       \
+    hipLaunchKernelGGL((k_kc_iter<KM, FULL>), dim3(grid), dim3(KM_BLOCK), 0, st, w.hdr, w.swh, w.slab, w.plab, w.pcell, w.pstart, \
+                       w.pcnt, w.psum, w.pbox, cent, (int)k, prev, out, zero, (long long *)history, slot, write_cent, (int)w.pmax)
+    const int kmax = km_kmax(k);
+    if (k == 5) KC_LAUNCH(5, true);
+    else if (kmax == 5) KC_LAUNCH(5, false);
+    else if (k == 9) KC_LAUNCH(9, true);
+    else if (kmax == 9) KC_LAUNCH(9, false);
+    else KC_LAUNCH(16, false);
+#undef KC_LAUNCH
+    DG_CHECK_LAUNCH("k_kc_iter");
+    return DG_OK;
+}
+
+// dg_kmeans_iou_run on a workspace dg_kmeans_prepare filled for these boxes: same results (cent, labels, acc, history),
+// the iterations before the last one over cells.
+extern "C" int dg_kmeans_iou_run_prepared(const float *wh, int64_t n, float *cent, int64_t k, uint8_t *labels, int64_t *acc,
+                                          int64_t *history, int64_t slot0, int64_t iters, void *ws, size_t ws_bytes, dg_stream_t s)
+{
+    DG_REQUIRE(iters >= 0, "kmeans_run_prepared: iters < 0");
+    int rc = km_check("kmeans_run_prepared", wh, n, cent, k, labels);
+    if (rc) return rc;
+    DG_REQUIRE(acc && n >= 1, "kmeans_run_prepared: null acc or no boxes");
+    DG_REQUIRE(ws && (((uintptr_t)ws) & 255) == 0, "kmeans_run_prepared: workspace null or not 256-byte aligned");
+    if (ws_bytes < dg_kmeans_prepared_workspace_bytes(n, k)) { dg_set_error("kmeans_run_prepared: workspace too small"); return DG_ENOMEM; }
+    if (iters == 0) return DG_OK;
+    hipStream_t st = (hipStream_t)s;
+    KcWs w = kc_layout(n, k, ws);
+    const size_t pe = dg_kmeans_part_elems(k);
+    // four buffers: three in rotation for the cell iterations (as dg_kmeans_iou_run), the fourth for the box-order pass
+    if (hipMemsetAsync(w.part[0], 0, (size_t)((char *)w.part[3] - (char *)w.part[0]) + pe * 8, st) != hipSuccess) { dg_set_error("kmeans_run_prepared: memset failed"); return DG_EHIP; }
+    for (int64_t t = 0; t < iters; ++t) {
+        const long long *prev = t ? w.part[(t - 1) % 3] : nullptr;
+        if (t + 1 == iters) {
+            // the last iteration twice from the same centroids: box order for labels / inertia / acc, cells for `changed`
+            if ((rc = km_launch(wh, n, cent, k, labels, (const int64_t *)prev, (int64_t *)w.part[3], nullptr, history, slot0 + t - 1, true, st))) return rc;
+            if ((rc = kc_launch(w, cent, k, prev, w.part[t % 3], nullptr, nullptr, 0, 0, st))) return rc;
+        } else {
+            if ((rc = kc_launch(w, cent, k, prev, w.part[t % 3], w.part[(t + 1) % 3], history, slot0 + t - 1, 1, st))) return rc;
+        }
+    }
+    if ((rc = km_finish((const int64_t *)w.part[3], k, cent, acc, nullptr, 0, st))) return rc;
+    hipLaunchKernelGGL(k_kc_changed, dim3(1), dim3(1), 0, st, w.part[(iters - 1) % 3], (int)k, (long long *)acc, (long long *)history, slot0 + iters - 1);
+    DG_CHECK_LAUNCH("k_kc_changed");
+    return DG_OK;
+}
