@@ -176,7 +176,11 @@ class _HipBackend:
         ops.kmeans_step(self.wh, self.cent, self.labels, self.acc)
 
     def history_host(self, upto):
-        return self.history[:upto].cpu().numpy()
+        h = self.history[:upto].cpu().numpy()
+        if (h < 0).any():       # the persistent kernel's grid barrier gave up (include/detgeom.h); never seen, but not silent
+            raise _abi.DetGeomError("k-means: the persistent iteration kernel abandoned its grid barrier (history holds -1); "
+                                    "set DG_KMEANS_PERSIST=0")
+        return h
 
     def results(self):
         return (self.cent.cpu().numpy(), ops.kmeans_labels_i32(self.labels).cpu().numpy(), self.acc.cpu().numpy())

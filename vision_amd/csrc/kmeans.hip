@@ -1048,6 +1048,194 @@ __global__ __launch_bounds__(KM_BLOCK) void k_kc_iter(const KcHdr *__restrict__ 
     }
 }
 
+// ---- all cell iterations of a run in ONE launch ---------------------------------------------------------------------
+// k_kc_iter's work is small (a decision per piece, a twentieth of the boxes walked): about 11 us per launch are launch,
+// the piece loads and the fold of the previous sums.  Here the workgroups stay: a thread keeps its piece (bounding box, sums,
+// range) in registers across iterations, and an iteration ends in a GRID BARRIER -- every workgroup adds its row into the
+// iteration's partial-sums buffer with device-scope atomics, bumps a counter and waits until all have, then folds the
+// buffer (loads that bypass the caches) and moves the centroids, exactly as the next launch's prologue would.  The grid is
+// at most what the device holds at once (occupancy query), so every workgroup is resident and the barrier cannot wait for
+// a workgroup that has not started; the wait is bounded all the same (about 0.2 s): a workgroup that gives up sets
+// hdr->error and writes -1 into the history slots it leaves undone, which the host side turns into an error.
+// Buffers rotate as in dg_kmeans_iou_run: iteration t adds into part[t % 3]; workgroup 0 zeroes part[(t + 1) % 3] BEFORE it
+// arrives at barrier t (that buffer was last read after barrier t - 2, and reaching iteration t means every workgroup has
+// passed barrier t - 1).
+#define KC_SPIN_LIMIT (1u << 20)
+template <int KMAX, bool FULL>
+__global__ __launch_bounds__(KM_BLOCK) void k_kc_persist(KcHdr *__restrict__ hdr, const float2 *__restrict__ swh,
+                                                         uint8_t *__restrict__ slab, uint8_t *__restrict__ plab,
+                                                         const int *__restrict__ pstart, const int *__restrict__ pcnt,
+                                                         const long long *__restrict__ psum, const float4 *__restrict__ pbox,
+                                                         float *cent, int k, long long *part0, long long *part1, long long *part2,
+                                                         long long *__restrict__ history, int64_t slot0, int iters, int pmax,
+                                                         unsigned *__restrict__ bar)
+{
+    constexpr int COLS = 3 * KMAX + 2;
+    __shared__ unsigned long long sacc_all[KMAX * 2 * KM_BLOCK];
+    __shared__ unsigned scnt_all[KMAX * KM_BLOCK];
+    __shared__ float2 scent[16];
+    __shared__ long long s_prev[3 * 16 + 2];
+    __shared__ int s_queue[KM_BLOCK], s_qstart[KM_BLOCK], s_qcnt[KM_BLOCK], s_qn, s_ok;
+    __shared__ unsigned s_changed[KM_BLOCK];
+    __shared__ unsigned long long s_cpart[COLS][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int pstride = km_stride(k), cols = 3 * k + 2;
+    const int G = (int)gridDim.x;
+    long long *part[3] = {part0, part1, part2};
+    // this thread's piece, for the whole run: slot tid of this workgroup (host: ceil(pmax / G) <= KM_BLOCK)
+    const int p = tid * G + (int)blockIdx.x;
+    int pst = 0, pc = 0;
+    long long ps0 = 0, ps1 = 0;
+    unsigned prevl = 255;
+    float4 bb = make_float4(1.f, 0.f, 1.f, 0.f);
+    if (p < pmax) { bb = pbox[p]; pst = pstart[p]; pc = pcnt[p]; ps0 = psum[2 * (size_t)p]; ps1 = psum[2 * (size_t)p + 1]; prevl = plab[p]; }
+    const bool valid = pc > 0;
+    if (tid < 16) scent[tid] = (tid < k) ? make_float2(cent[2 * tid], cent[2 * tid + 1]) : make_float2(0.f, 0.f);
+    __syncthreads();
+    for (int t = 0; t < iters; ++t) {
+        float cw[KMAX], ch[KMAX];
+        bool cent_ok = true;
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c) {
+            cw[c] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(scent[c < 16 ? c : 0].x)));
+            ch[c] = __uint_as_float(__builtin_amdgcn_readfirstlane(__float_as_uint(scent[c < 16 ? c : 0].y)));
+            if (FULL || c < k) cent_ok = cent_ok && (cw[c] > 0.0f) && (ch[c] > 0.0f) && (cw[c] * ch[c] < 0x1p60f);
+        }
+        const unsigned gap_min = cent_ok ? KM_GAP_MIN : 0xffffffffu;
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c) {
+            sacc_all[(c * 2 + 0) * KM_BLOCK + tid] = 0;
+            sacc_all[(c * 2 + 1) * KM_BLOCK + tid] = 0;
+            scnt_all[c * KM_BLOCK + tid] = 0;
+        }
+        if (tid == 0) s_qn = 0;
+        if (blockIdx.x == 0)
+            for (int z = tid; z < KM_REPL * pstride; z += KM_BLOCK) part[(t + 1) % 3][z] = 0;
+        __syncthreads();
+        unsigned long long *sacc = sacc_all + tid;
+        unsigned *scnt = scnt_all + tid;
+        unsigned long long inertia = 0;
+        int changed = 0;
+        if (valid) {
+            const int L = cent_ok ? kc_decide<KMAX, FULL>(bb, cw, ch, k) : 255;
+            if (L != 255) {
+                atomicAdd(&sacc[(L * 2 + 0) * KM_BLOCK], (unsigned long long)ps0 + (unsigned long long)pc * KM_MAGIC);
+                atomicAdd(&sacc[(L * 2 + 1) * KM_BLOCK], (unsigned long long)ps1 + (unsigned long long)pc * KM_MAGIC);
+                atomicAdd(&scnt[L * KM_BLOCK], (unsigned)pc);
+                if (prevl == 255u) {
+                    int ch_ = 0;
+                    for (int j = 0; j < pc; ++j) ch_ += slab[pst + j] != (uint8_t)L;
+                    changed += ch_;
+                } else if (prevl != (unsigned)L) {
+                    changed += pc;
+                }
+                prevl = (unsigned)L;
+            } else {
+                const int at = atomicAdd(&s_qn, 1);
+                s_queue[at] = tid; s_qstart[at] = pst; s_qcnt[at] = pc | ((int)prevl << 16);
+                prevl = 255u;
+            }
+        }
+        __syncthreads();
+        const int qn = s_qn;
+        for (int qi = wave; qi < qn; qi += KM_BLOCK / 64) {
+            const int qs = s_qstart[qi], qc = s_qcnt[qi] & 0xffff;
+            const unsigned ql = (unsigned)s_qcnt[qi] >> 16;
+#pragma unroll
+            for (int j = 0; j < KC_PIECE / 64; ++j) {
+                const int o = lane + 64 * j;
+                if (o < qc) {
+                    const float2 b = swh[qs + o];
+                    const unsigned old = (ql == 255u) ? (unsigned)slab[qs + o] : ql;
+                    int best;
+                    float bd = 0.f;
+                    if (!(km_filter<KMAX, FULL>(b.x, b.y, cw, ch, k, gap_min, best) && (fabsf(b.x) + fabsf(b.y)) < KM_FAST_LIMIT))
+                        best = km_assign<KMAX, FULL>(b.x, b.y, cw, ch, k, bd);
+                    if ((fabsf(b.x) + fabsf(b.y)) < KM_FAST_LIMIT) km_accum<true, false>(b.x, b.y, 0.f, best, sacc, scnt, inertia, changed, slab + qs + o, old);
+                    else km_accum<false, false>(b.x, b.y, 0.f, best, sacc, scnt, inertia, changed, slab + qs + o, old);
+                }
+            }
+        }
+        s_changed[tid] = (unsigned)changed;
+        __syncthreads();
+        {
+            const int sub = tid & 15;
+            for (int col = tid >> 4; col < COLS; col += KM_BLOCK / 16) {
+                unsigned long long v = 0;
+                if (col < 2 * KMAX) {
+                    const unsigned long long *src = sacc_all + ((col % KMAX) * 2 + col / KMAX) * KM_BLOCK;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) v += src[j * 16 + sub];
+                } else if (col < 3 * KMAX) {
+                    const unsigned *src = scnt_all + (col - 2 * KMAX) * KM_BLOCK;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) v += src[j * 16 + sub];
+                } else if (col == 3 * KMAX) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) v += s_changed[j * 16 + sub];
+                }
+                s_cpart[col][sub] = v;
+            }
+        }
+        __syncthreads();
+        if (tid < COLS) {
+            unsigned long long v = 0;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) v += s_cpart[tid][j];
+            const int grp = tid / KMAX, c = tid - grp * KMAX;
+            if (grp < 2) {
+                unsigned long long cnt = 0;
+#pragma unroll
+                for (int j = 0; j < 16; ++j) cnt += s_cpart[2 * KMAX + c][j];
+                v -= cnt * KM_MAGIC;
+            }
+            const int col = (grp < 3) ? (c < k ? grp * k + c : -1) : 3 * k + c;
+            if (col >= 0 && v != 0)
+                atomicAdd(reinterpret_cast<unsigned long long *>(part[t % 3]) + (blockIdx.x % KM_REPL) * pstride + col, v);
+        }
+        // ---- grid barrier t: every workgroup's row is in part[t % 3] (and workgroup 0's zeroing of the next buffer is out)
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) {
+            atomicAdd(bar, 1u);
+            const unsigned target = (unsigned)G * (unsigned)(t + 1);
+            unsigned spins = 0;
+            int ok = 1;
+            while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > KC_SPIN_LIMIT) { ok = 0; break; }
+            }
+            s_ok = ok;
+        }
+        __syncthreads();
+        if (!s_ok) {                                             // uniform: give up, loudly
+            if (tid == 0) {
+                hdr->pad[0] = 1;
+                if (blockIdx.x == 0 && history) for (int u = t; u < iters; ++u) history[slot0 + u] = -1;
+            }
+            break;
+        }
+        // ---- fold iteration t's sums (coherent loads: other workgroups' atomics went to memory), move the centroids
+        if (tid < cols) {
+            long long v = 0;
+#pragma unroll
+            for (int r = 0; r < KM_REPL; ++r) v += __hip_atomic_load(part[t % 3] + r * pstride + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_prev[tid] = v;
+        }
+        __syncthreads();
+        if (tid < k) {
+            float2 c = scent[tid];
+            const long long cnt = s_prev[2 * k + tid];
+            if (cnt > 0) { c.x = km_centroid(s_prev[tid], cnt); c.y = km_centroid(s_prev[k + tid], cnt); }
+            scent[tid] = c;
+            if (blockIdx.x == 0) { cent[2 * tid] = c.x; cent[2 * tid + 1] = c.y; }
+        }
+        if (blockIdx.x == 0 && tid == 0 && history) history[slot0 + t] = s_prev[3 * k];
+        __syncthreads();
+    }
+    if (valid) plab[p] = (uint8_t)prevl;                         // the piece's label state for the next launch on this workspace
+}
+
 // history[slot] and acc[3k] <- the changed count of the cell pass (the box-order pass that produced acc compares with the
 // caller's label array, which the cell iterations do not keep up to date)
 __global__ void k_kc_changed(const long long *__restrict__ part, int k, long long *__restrict__ acc, long long *__restrict__ history,
@@ -1124,8 +1312,36 @@ extern "C" int dg_kmeans_iou_run_prepared(const float *wh, int64_t n, float *cen
     const size_t pe = dg_kmeans_part_elems(k);
     // four buffers: three in rotation for the cell iterations (as dg_kmeans_iou_run), the fourth for the box-order pass
     if (hipMemsetAsync(w.part[0], 0, (size_t)((char *)w.part[3] - (char *)w.part[0]) + pe * 8, st) != hipSuccess) { dg_set_error("kmeans_run_prepared: memset failed"); return DG_EHIP; }
-    for (int64_t t = 0; t < iters; ++t) {
-        const long long *prev = t ? w.part[(t - 1) % 3] : nullptr;
+    // default: one launch per cell iteration (k_kc_iter); DG_KMEANS_PERSIST=1: all of them in one launch (k_kc_persist, a grid
+    // barrier per iteration -- measured slower on this part, see DESIGN.md: kept for the measurement and as the structure a
+    // peer-mapped exchange between GPUs would need)
+    const bool persist_on = getenv("DG_KMEANS_PERSIST") && atoi(getenv("DG_KMEANS_PERSIST")) != 0;
+    int64_t t0 = 0;
+    if (persist_on && iters >= 2) {
+        const int kmax = km_kmax(k);
+        int resident;
+#define KC_RES(KM, FULL) resident = km_resident_blocks(k_kc_persist<KM, FULL>)
+        if (k == 5) KC_RES(5, true); else if (kmax == 5) KC_RES(5, false); else if (k == 9) KC_RES(9, true); else if (kmax == 9) KC_RES(9, false); else KC_RES(16, false);
+#undef KC_RES
+        int64_t G = (w.pmax + KC_WG_PIECES - 1) / KC_WG_PIECES;
+        if (G > resident) G = resident;
+        if (getenv("DG_KMEANS_PERSIST_G") && atoi(getenv("DG_KMEANS_PERSIST_G")) > 0 && atoi(getenv("DG_KMEANS_PERSIST_G")) < G) G = atoi(getenv("DG_KMEANS_PERSIST_G"));
+        if ((w.pmax + G - 1) / G <= KM_BLOCK) {                       // a piece per thread at most
+            unsigned *bar = (unsigned *)&w.hdr->pad[1];
+            if (hipMemsetAsync(&w.hdr->pad[0], 0, 16, st) != hipSuccess) { dg_set_error("kmeans_run_prepared: memset failed"); return DG_EHIP; }
+#define KC_PERSIST(KM, FULL)                                                                                                       \
+            hipLaunchKernelGGL((k_kc_persist<KM, FULL>), dim3((unsigned)G), dim3(KM_BLOCK), 0, st, w.hdr, w.swh, w.slab, w.plab, w.pstart, \
+                               w.pcnt, w.psum, w.pbox, cent, (int)k, w.part[0], w.part[1], w.part[2], (long long *)history, slot0,       \
+                               (int)(iters - 1), (int)w.pmax, bar)
+            if (k == 5) KC_PERSIST(5, true); else if (kmax == 5) KC_PERSIST(5, false); else if (k == 9) KC_PERSIST(9, true);
+            else if (kmax == 9) KC_PERSIST(9, false); else KC_PERSIST(16, false);
+#undef KC_PERSIST
+            DG_CHECK_LAUNCH("k_kc_persist");
+            t0 = iters - 1;                                         // the centroids of the last iteration are in `cent` now
+        }
+    }
+    for (int64_t t = t0; t < iters; ++t) {
+        const long long *prev = (t && !t0) ? w.part[(t - 1) % 3] : nullptr;
         if (t + 1 == iters) {
             // the last iteration twice from the same centroids: box order for labels / inertia / acc, cells for `changed`
             if ((rc = km_launch(wh, n, cent, k, labels, (const int64_t *)prev, (int64_t *)w.part[3], nullptr, history, slot0 + t - 1, true, st))) return rc;
