@@ -265,7 +265,8 @@ def extra_single_image(d):
         t = ev_median(w.nms, 100, 20)
         r[f"nms2000_thr{thr}_ms"] = t
         r[f"nms2000_thr{thr}_boxes_per_s"] = 2000 / t * 1e3
-    r["note"] = "config 1; NMS at N=2000 is launch-latency-bound (6 kernels); median of 100 launches after 20 warm-up"
+    r["note"] = ("config 1; NMS at N=2000 is launch-latency-bound (3 kernels: LDS bitonic sort, mask, fixed-point keep list from the "
+                 "mask's non-zero words); median of 100 launches after 20 warm-up")
     return r
 
 
@@ -360,13 +361,23 @@ def extra_stress(d, n=65536):
             t_mask = ev_median(lambda: lib.dg_nms_phase_mask(None, 1, n, thr, _abi.ptr(ws), nb, sp), 50, 20)
             t_red = ev_median(lambda: lib.dg_nms_phase_reduce(None, 1, n, 1, _abi.ptr(keep), _abi.ptr(kc), _abi.ptr(ws), nb, sp), 50, 20)
             tot = t_sort + t_mask + t_red
-            r[tag] = {"sort_ms": t_sort, "mask_ms": t_mask, "reduce_ms": t_red, "kept": int(kc.item()),
-                      "boxes_per_s": n / tot * 1e3,
-                      "mask_hbm_frac": (n * n / 16.0 + 20 * n) / (t_mask * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                      "mask_valu_frac": valu_frac("k_nms_mask", n, t_mask)}
-    r["note"] = ("config 5 (replicas only); mask bytes = upper-triangular N^2/16 written; k_nms_mask is VALU-bound (IoU test of "
-                 "N^2/2 pairs): mask_valu_frac = SQ_INSTS_VALU x 64 / time over the chip's 7.86e13 lane-ops/s; reduce is a serial chain; "
-                 "medians of 50 launches after 20 warm-up")
+            t_all = ev_median(lambda: ops.nms_batched(bt, st, None, thr, True, keep=keep, keep_count=kc), 50, 20)
+            mode, fpdone, rounds, npairs = ops.nms_path_info(d.dev, 1, n)
+            kept = int(kc.item())
+            a_n = 20.0 * n + n * n / 4.0 + 8.0 * kept            # A(N) = 20 N + N^2/8 written + N^2/8 read + 8 K
+            r[tag] = {"sort_ms": t_sort, "mask_ms": t_mask, "reduce_ms": t_red, "whole_call_ms": t_all, "kept": kept,
+                      "boxes_per_s": n / t_all * 1e3,
+                      "path": ("pruned: x-bucket band pair search + fixed-point keep list" if mode == 0 else "dense mask"),
+                      "fixed_point_rounds": rounds if mode == 0 and fpdone else None, "suppressing_pairs": npairs if mode == 0 else None,
+                      "survey_A_N_frac": a_n / (t_all * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                      "mask_hbm_frac": ((n * n / 16.0 + 20 * n) / (t_mask * 1e-3) / 1e9 / HBM_PEAK_GBPS) if mode == 1 else None,
+                      "mask_valu_frac": valu_frac("k_nms_mask", n, t_mask) if mode == 1 else None}
+    r["note"] = ("config 5 (replicas only).  survey_A_N_frac = SURVEY 8(d)'s A(N) (which prices an N x N mask written and read) over "
+                 "the whole call's time and 8 TB/s: the pruned path never forms that mask -- pairs of boxes that do not overlap cannot "
+                 "suppress, so it searches a band of the x-bucket order and moves a few MB -- which is why this is an equivalent rate, "
+                 "not memory traffic; dense sets take the dense mask (k_nms_mask, VALU-bound: mask_valu_frac = SQ_INSTS_VALU x 64 / time "
+                 "over the chip's 7.86e13 lane-ops/s); phases are timed one by one (sort includes the x-bucket sort of the pruned "
+                 "path), whole_call_ms is dg_nms_batched_f32 as one call; medians of 50 launches after 20 warm-up")
     return r
 
 
@@ -417,6 +428,30 @@ def extra_kmeans(d, n_total=10_000_000, iters=30):
                  "run only, on one rank and on many alike; device_ms_per_iter = HIP-event time of the same 30 iterations / 30 "
                  "(k_kmeans_step is VALU-bound: iter_valu_frac = SQ_INSTS_VALU x 64 / time over the chip's 7.86e13 lane-ops/s)"}
     km.close()                                   # frees the library-side communicator, if this fit made one (collective)
+    if d.world == 1 and not d.rehearse:
+        # round 3: the single-device fit runs PREPARED (boxes grouped by (w,h) cell once per fit, iterations over pieces of
+        # cells; dg_kmeans_prepare / dg_kmeans_iou_run_prepared) -- the figures above are that path.  The box-by-box loop
+        # (k_kmeans_step every iteration, what the sharded fit still runs) beside it, with its HBM fraction at SURVEY's
+        # 12 B/box and at the bytes the kernel really moves (8 B box + 1 B old label + 1 B new label = 10 B/box)
+        r["path"] = "prepared (cells)" if getattr(km._backend, "cells", None) is not None else "box loop"
+        r["iter_hbm_frac_note"] = ("the prepared iterations do not read the boxes they decide piece-wise, so SURVEY's 12 B/box over "
+                                   "their time is an equivalent rate, not memory traffic")
+        try:
+            os.environ["DG_KMEANS_CELLS"] = "0"
+            kb = cluster.kmean(5, 42)
+            kb.fit(shard, init_centers=init, fixed_iters=iters)
+            msb = min(ev_time(lambda: kb._run_iters(0, iters), 3, 1) for _ in range(3)) / iters
+            r["box_loop"] = {"device_ms_per_iter": msb, "iters_per_s": 1e3 / msb, "iter_hbm_frac_12B": (12.0 * per) / (msb * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                             "iter_hbm_frac_own_10B": (10.0 * per) / (msb * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                             "iter_valu_frac": valu_frac("k_kmeans_step", per, msb),
+                             "same_centers": bool(np.array_equal(kb.cluster_centers_, km.cluster_centers_))}
+            os.environ["DG_KMEANS_CELLS"] = "1"
+            t0 = time.perf_counter(); kp = cluster.kmean(5, 42); kp.fit(shard, init_centers=init, fixed_iters=iters); torch.cuda.synchronize()
+            r["fit_30_iters_wall_ms_incl_prepare"] = (time.perf_counter() - t0) * 1e3
+        except Exception as e:  # noqa: BLE001
+            r["box_loop"] = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            os.environ.pop("DG_KMEANS_CELLS", None)
     if d.world == 1 and not d.rehearse:
         # what the sharded loop costs per iteration on a 1/8 shard (1.25 M boxes), all-reduce included, on this one GPU:
         # a single-rank RCCL group runs the same launch + all-reduce sequence the 8-GPU job runs on every rank

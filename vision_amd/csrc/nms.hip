@@ -1373,6 +1373,13 @@ __global__ __launch_bounds__(256) void k_nms_xb_scatter(const float *__restrict_
     bar[p] = make_float2(sarea[o + i], __int_as_float((int)i | (endtile << 16)));
 }
 
+// the mask phase on its own (dg_nms_phase_mask called again on a sorted workspace, as bench.py times it): the pair list starts empty
+__global__ void k_nms_reset_pairs(NmsHdr *__restrict__ hdr, int batch)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < batch) hdr[i].npairs = 0;
+}
+
 __global__ void k_nms_force_dense(NmsHdr *__restrict__ hdr, int batch)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1847,8 +1854,8 @@ case 512: launch_sort_small<512>(w, boxes, scores, counts, batch, nmax, st); bre
     return DG_OK;
 }
 
-extern "C" int dg_nms_phase_mask(const int32_t *counts, int64_t batch, int64_t nmax, float threshold,
-                                 void *ws, size_t ws_bytes, dg_stream_t s)
+static int nms_phase_mask(const int32_t *counts, int64_t batch, int64_t nmax, float threshold, void *ws, size_t ws_bytes, dg_stream_t s,
+                          bool standalone)
 {
     NmsWs w;
     int rc = nms_check("nms_mask", batch, nmax, ws, ws_bytes, &w);
@@ -1865,6 +1872,7 @@ extern "C" int dg_nms_phase_mask(const int32_t *counts, int64_t batch, int64_t n
     if (w.pruned && nms_prune_mode() != 0) {
         // the pruned pair search for the images k_nms_xbucket chose (hdr.mode == 0); the dense mask below runs for the others
         hdr = w.hdr;
+        if (standalone) hipLaunchKernelGGL(k_nms_reset_pairs, dim3((unsigned)dg_cdiv(batch, 256)), dim3(256), 0, (hipStream_t)s, w.hdr, (int)batch);
         if (!fast_ok) {
             hipLaunchKernelGGL(k_nms_force_dense, dim3((unsigned)dg_cdiv(batch, 256)), dim3(256), 0, (hipStream_t)s, w.hdr, (int)batch);
         } else {
@@ -1889,6 +1897,12 @@ extern "C" int dg_nms_phase_mask(const int32_t *counts, int64_t batch, int64_t n
 #undef MASK_LAUNCH
     DG_CHECK_LAUNCH("k_nms_mask");
     return DG_OK;
+}
+
+extern "C" int dg_nms_phase_mask(const int32_t *counts, int64_t batch, int64_t nmax, float threshold,
+                                 void *ws, size_t ws_bytes, dg_stream_t s)
+{
+    return nms_phase_mask(counts, batch, nmax, threshold, ws, ws_bytes, s, true);
 }
 
 extern "C" int dg_nms_phase_reduce(const int32_t *counts, int64_t batch, int64_t nmax, int quirk_drop_last,
@@ -1970,7 +1984,7 @@ extern "C" int dg_nms_batched_f32(const float *boxes, const float *scores, const
 {
     int rc = dg_nms_phase_sort(boxes, scores, counts, batch, nmax, ws, ws_bytes, s);
     if (rc) return rc;
-    rc = dg_nms_phase_mask(counts, batch, nmax, threshold, ws, ws_bytes, s);
+    rc = nms_phase_mask(counts, batch, nmax, threshold, ws, ws_bytes, s, false);
     if (rc) return rc;
     return dg_nms_phase_reduce(counts, batch, nmax, quirk_drop_last, keep, keep_count, ws, ws_bytes, s);
 }
