@@ -362,7 +362,7 @@ def extra_stress(d, n=65536):
             t_red = ev_median(lambda: lib.dg_nms_phase_reduce(None, 1, n, 1, _abi.ptr(keep), _abi.ptr(kc), _abi.ptr(ws), nb, sp), 50, 20)
             tot = t_sort + t_mask + t_red
             t_all = ev_median(lambda: ops.nms_batched(bt, st, None, thr, True, keep=keep, keep_count=kc), 50, 20)
-            mode, fpdone, rounds, npairs = ops.nms_path_info(d.dev, 1, n)
+            mode, fpdone, rounds, npairs = ops.nms_path_info(d.dev, 1, n)[:4]
             kept = int(kc.item())
             a_n = 20.0 * n + n * n / 4.0 + 8.0 * kept            # A(N) = 20 N + N^2/8 written + N^2/8 read + 8 K
             r[tag] = {"sort_ms": t_sort, "mask_ms": t_mask, "reduce_ms": t_red, "whole_call_ms": t_all, "kept": kept,

@@ -214,7 +214,7 @@ def test_config3_full_size_batched_nms_256_images_vs_oracle(va, thr):
 @pytest.mark.parametrize("dense,thr,quirk", [(False, 0.5, True), (False, 0.7, True), (False, 0.3, False), (True, 0.5, True), (True, 0.7, False)])
 def test_nms_64k_vs_oracle(va, dense, thr, quirk):
     """config 5 (yolo/yolo_v1/yolo.py:188-203 on 65,536 boxes): the keep list, bit for bit, against the C oracle; sparse sets
-    take the pruned pair search + fixed-point keep list, dense ones the dense mask, and the test says which ran."""
+    and dense sets alike take the pruned pair search + fixed-point keep list at these thresholds, and the test checks that."""
     from oracle import oracle as orc
     from vision_amd import ops
     orc.build()
@@ -222,10 +222,10 @@ def test_nms_64k_vs_oracle(va, dense, thr, quirk):
     bt, st = torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()
     keep, cnt = ops.nms_batched(bt[None], st[None], None, thr, quirk)
     got = keep[0, :int(cnt[0])].cpu().numpy()
-    mode, fpdone, rounds, npairs = ops.nms_path_info(bt.device, 1, 65536)
-    assert mode == (1 if dense else 0), (mode, fpdone, rounds, npairs)
-    if not dense:
-        assert fpdone == 1 and 0 < rounds < 64 and npairs > 0
+    mode, fpdone, rounds, npairs, cpb, est = ops.nms_path_info(bt.device, 1, 65536)
+    # all five take the pruned path (the dense set has about 70 suppressing pairs per box at 0.5, under the 128 the estimate allows)
+    assert mode == 0 and fpdone == 1 and 0 < rounds < 64 and npairs > 0, (mode, fpdone, rounds, npairs, cpb, est)
+    assert 0.5 * npairs <= est * 65536 + 65536 and est * 65536 <= 2 * npairs + 65536, (npairs, est)   # the sampled estimate is about right
     want = orc.nms(b, s, thr, quirk)
     assert len(got) == len(want) and np.array_equal(got, want)
 
@@ -250,6 +250,12 @@ def test_nms_64k_fallbacks_vs_oracle(va, monkeypatch):
     keep, cnt = ops.nms_batched(bt[None], st[None], None, 0.7, True)
     assert ops.nms_path_info(bt.device, 1, 65536)[:2] == (0, 1)
     assert np.array_equal(keep[0, :int(cnt[0])].cpu().numpy(), orc.nms(b, s, 0.7, True))
+    # 0.3 on the dense set: about 400 pairs per box -- the estimate sends the image to the dense mask (unless forced: above)
+    monkeypatch.setenv("DG_NMS_PRUNE", "1")
+    keep, cnt = ops.nms_batched(bt[None], st[None], None, 0.3, True)
+    info = ops.nms_path_info(bt.device, 1, 65536)
+    assert info[0] == 1 and info[5] > 128, info
+    assert np.array_equal(keep[0, :int(cnt[0])].cpu().numpy(), orc.nms(b, s, 0.3, True))
 
 
 def test_pairwise_64k_rows_vs_oracle(va):

@@ -141,10 +141,11 @@ def test_nms_small_image_rounds_and_serial_vs_oracle(va, oracle, fb, monkeypatch
 
 @pytest.mark.parametrize("prune,rounds", [("1", None), ("2", None), ("2", "0"), ("2", "1"), ("2", "3"), ("0", None)])
 def test_nms_pruned_path_vs_oracle(va, oracle, prune, rounds, monkeypatch):
-    """The pruned path of large images (x-bucket band pair search, flat pair list, fixed-point keep list) and its fallbacks:
-    DG_NMS_PRUNE=2 takes it whatever the candidate count, DG_NMS_FP_ROUNDS cuts the fixed point off after that many rounds
-    (the serial chain over the grouped pair list finishes), 0 = the dense mask only.  Sparse and dense sets, degenerate
-    boxes, ragged batches, a ladder (one round per box), identical boxes (every pair suppresses); against the oracle."""
+    """The pruned path of large images (x-bucket band pair search, 64 pair lists by target rank, fixed-point keep list on 64
+    workgroups) and its fallbacks: DG_NMS_PRUNE=2 takes it whatever the candidate count, DG_NMS_FP_ROUNDS cuts the fixed point
+    off after that many rounds (the serial chain over the grouped pairs finishes), DG_NMS_PRUNE=0 = the dense mask only.
+    Sparse and dense sets, degenerate boxes, ragged batches, a ladder (one round per box), identical boxes (every pair
+    suppresses); against the oracle."""
     from vision_amd import ops
     monkeypatch.setenv("DG_NMS_PRUNE", prune)
     if rounds is not None:
@@ -173,7 +174,8 @@ def test_nms_pruned_path_vs_oracle(va, oracle, prune, rounds, monkeypatch):
                 if prune == "0" or not np.isfinite(boxes).all():
                     assert info[0] == 1, info
                 elif prune == "2":
-                    assert info[0] == 0 or info[3] > 32 * boxes.shape[1], info      # pruned unless the pair list overflowed
+                    lcap = (-(-boxes.shape[1] // 64)) ** 2                          # entries one of the image's 64 pair lists holds
+                    assert info[0] == 0 or info[3] > lcap - 4, info                 # pruned unless a pair list overflowed
                     if info[0] == 0 and rounds == "0" and info[3] > 0:
                         assert info[1] == 0, info                                   # the serial chain finished the image
                 for i in range(boxes.shape[0]):

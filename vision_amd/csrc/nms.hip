@@ -23,12 +23,17 @@
 struct NmsHdr {
     float xmin, scale;       // x-bucket of a coordinate: clamp((x - xmin) * scale, 0, XB_G - 1)
     int32_t mode;            // 0: pruned path (banded pair search in x-bucket order); 1: dense mask
-    int32_t fpdone;          // k_nms_resolve_fp converged and wrote the keep list
+    int32_t fpdone;          // k_nms_resolve_mc converged and wrote the keep list
     int32_t rounds;          // rounds it took (diagnostic)
-    int32_t npairs;          // suppressing pairs k_nms_band found (entries of the flat pair list; > ecap: overflow, mode -> 1)
-    int32_t pad[10];
+    int32_t npairs;          // suppressing pairs k_nms_band found (all 64 lists; written by k_nms_resolve_mc)
+    int32_t cpb;             // candidate pairs per box, as k_nms_xbucket estimated them
+    uint32_t estsum;         // k_nms_estimate: suppressing pairs of 1024 sampled boxes (x n / 1024 = the image's)
+    int32_t pad[8];
 };
 
+// the 64 list cursors of an image: 128 bytes apart -- device-scope atomics are carried out at the memory side, line by line,
+// and 64 hot counters in two lines made k_nms_band 37 us slower than one cursor had
+#define LC_STRIDE 32
 struct NmsWs {
     int64_t Np, W, SW, Np2;
     u64 *keys;
@@ -49,6 +54,10 @@ struct NmsWs {
     float2 *bar;
     int32_t *pos, *start;
     u64 *diag;
+    int64_t lcap;            // entries each of an image's 64 pair lists (and 64 work lists) holds: they share the image's dense mask
+    int lsh;                 // a pair's list: higher rank >> lsh
+    int32_t *lcnt;           // [batch][64][LC_STRIDE] entries in each list, every counter in a 128-byte line of its own
+    u32 *mc;                 // [batch][MC_WORDS] what the workgroups of k_nms_resolve_mc tell each other
     size_t total;
 };
 
@@ -80,9 +89,12 @@ static NmsWs nms_layout(int64_t batch, int64_t nmax, void *base)
     w.cflag = (int32_t *)take((size_t)batch * 4);
     w.ekey = (u32 *)take((size_t)batch * (w.ecap + 8) * 4);      // + CSR_SLACK
     w.eval = (u64 *)take((size_t)batch * (w.ecap + 8) * 8);
-    // (the pruned path's work lists -- two of ecap u32 per image -- live in the image's part of `mask`, which that path
-    //  never touches: Np * W * 8 >= 2 * 32 * Np * 4 bytes from W = 32 on)
+    // (the pruned path's 64 pair lists and 64 work lists per image live in the image's part of `mask`, which that path never
+    //  touches: Np * W * 2 u32 words, 128 lists of Np * W / 64 entries)
     w.pruned = (w.W > 64 && w.W <= 1024) ? 1 : 0;
+    w.lcap = (w.Np * w.W / 64) & ~(int64_t)3;
+    w.lsh = 7;
+    while ((64ll << w.lsh) < w.Np) ++w.lsh;
     if (w.pruned) {
         w.hdr = (struct NmsHdr *)take((size_t)batch * 64);
         w.bbox = (float4 *)take((size_t)batch * w.Np * 16);
@@ -90,8 +102,11 @@ static NmsWs nms_layout(int64_t batch, int64_t nmax, void *base)
         w.pos = (int32_t *)take((size_t)batch * w.Np * 4);
         w.start = (int32_t *)take((size_t)batch * (4096 + 1) * 4);       // XB_G + 1
         w.diag = (u64 *)take((size_t)batch * w.Np * 8);
+        w.lcnt = (int32_t *)take((size_t)batch * 64 * 32 * 4);           // LC_STRIDE
+        w.mc = (u32 *)take((size_t)batch * 4352 * 4);                    // MC_WORDS
     } else {
         w.hdr = nullptr; w.bbox = nullptr; w.bar = nullptr; w.pos = nullptr; w.start = nullptr; w.diag = nullptr;
+        w.lcnt = nullptr; w.mc = nullptr;
     }
     w.total = off;
     return w;
@@ -450,7 +465,7 @@ __global__ __launch_bounds__(T) void k_nms_reduce(const u64 *__restrict__ mask, 
 // 64-row blocks paid a compaction launch (k_nms_csr_build_small, 13 us) and about 0.7 us per block (25-50 us for one
 // 2000-box image); here ONE launch gathers the non-zero mask words of the image into LDS -- (row << 16 | word, bits), found
 // through the row summaries, every word's load in flight at once -- and then decides the boxes in ROUNDS like
-// k_nms_resolve_fp (see there), all entries in registers, the four bit sets in LDS: a round is two barriers.  More entries
+// k_nms_resolve_mc (see there), all entries in registers, the four bit sets in LDS: a round is two barriers.  More entries
 // than the LDS holds, or no end after max_rounds, and the serial chain over the dense mask finishes the image instead.
 #define RS_CAP 8192
 #define RS_PER (RS_CAP / 1024)
@@ -996,7 +1011,7 @@ __global__ __launch_bounds__(1024) void k_nms_csr_build_small(const u64 *__restr
     }
 }
 
-// SEG (the pruned path's fallback, when k_nms_resolve_fp gave up): a prologue first groups k_nms_band's flat pair list
+// SEG (the pruned path's fallback, when k_nms_resolve_mc gave up): a prologue first groups k_nms_band's flat pair list
 // (`ekey` = (lower rank << 16 | higher rank) entries, hdr.npairs of them) into per-block runs -- keys into the image's unused
 // dense-mask memory, values into `eval` -- and builds the diagonal words in diag[]; entries of a block's own word column
 // are skipped by the chain (the diagonal words carry them).
@@ -1006,7 +1021,8 @@ __global__ __launch_bounds__(1024) void k_nms_reduce_csr(const u64 *__restrict__
                                                          int64_t ecap, const int32_t *__restrict__ cflag, const int32_t *__restrict__ boff,
                                                          const u32 *__restrict__ ekey, const u64 *__restrict__ eval, int quirk,
                                                          int64_t *__restrict__ keep, int32_t *__restrict__ keep_count,
-                                                         const NmsHdr *__restrict__ hdr, const u64 *__restrict__ diag)
+                                                         const NmsHdr *__restrict__ hdr, const u64 *__restrict__ diag,
+                                                         const int32_t *__restrict__ lcnt, int64_t lcap)
 {
     __shared__ u64 remv[1024];
     __shared__ __attribute__((aligned(16))) u64 s_val[2][CSR_LDS_ENTRIES];
@@ -1040,13 +1056,18 @@ __global__ __launch_bounds__(1024) void k_nms_reduce_csr(const u64 *__restrict__
         // group the flat pair list by the lower rank's block: count, scan, scatter (one workgroup; this is the rare path)
         __shared__ int32_t s_cur[1024];
         __shared__ int s_wsum[16];
-        u32 *rkey = (u32 *)const_cast<u64 *>(mask);
+        u32 *rkey = const_cast<u32 *>(ekey);                  // (at most ecap pairs come here: k_nms_resolve_mc made sure)
         u64 *rval = const_cast<u64 *>(eval), *dg = const_cast<u64 *>(diag);
-        const int E = hdr[img].npairs;
+        const u32 *lists = (const u32 *)mask;                 // the image's 64 pair lists (k_nms_band)
+        lcnt += img * 64 * LC_STRIDE;
         s_blen[tid] = 0;
         for (int i = tid; i < nb * 64; i += 1024) dg[i] = 0ull;
         __syncthreads();
-        for (int e = tid; e < E; e += 1024) atomicAdd(&s_blen[ekey[e] >> 22], 1);
+        for (int g = 0; g < 64; ++g) {
+            const int E = lcnt[g * LC_STRIDE];
+            const u32 *lg = lists + (int64_t)g * lcap;
+            for (int e = tid; e < E; e += 1024) atomicAdd(&s_blen[lg[e] >> 22], 1);
+        }
         __syncthreads();
         {
             const int v = s_blen[tid];
@@ -1061,15 +1082,18 @@ __global__ __launch_bounds__(1024) void k_nms_reduce_csr(const u64 *__restrict__
             s_cur[tid] = base + incl - v;
         }
         __syncthreads();
-        for (int e = tid; e < E; e += 1024) {
-            const u32 key = ekey[e], lo = key >> 16, hi = key & 0xffffu;
-            const int at = atomicAdd(&s_cur[lo >> 6], 1);
-            rkey[at] = ((lo & 63u) << 16) | (hi >> 6);
-            rval[at] = 1ull << (hi & 63u);
-            if ((hi >> 6) == (lo >> 6)) atomicOr((unsigned long long *)&dg[lo], 1ull << (hi & 63u));
+        for (int g = 0; g < 64; ++g) {
+            const int E = lcnt[g * LC_STRIDE];
+            const u32 *lg = lists + (int64_t)g * lcap;
+            for (int e = tid; e < E; e += 1024) {
+                const u32 key = lg[e], lo = key >> 16, hi = key & 0xffffu;
+                const int at = atomicAdd(&s_cur[lo >> 6], 1);
+                rkey[at] = ((lo & 63u) << 16) | (hi >> 6);
+                rval[at] = 1ull << (hi & 63u);
+                if ((hi >> 6) == (lo >> 6)) atomicOr((unsigned long long *)&dg[lo], 1ull << (hi & 63u));
+            }
         }
         __syncthreads();                                      // the runs were written by this workgroup: visible to it from here on
-        ekey = rkey;
     } else {
         for (int w = tid; w < nb; w += 1024) { const int o = boff[w]; s_boff[w] = o; s_blen[w] = boff[w + 1] - o; }
     }
@@ -1210,7 +1234,7 @@ __global__ __launch_bounds__(1024) void k_nms_reduce_csr(const u64 *__restrict__
 //                   position; the exact number of candidate pairs decides between this path and the dense mask (hdr.mode);
 //   k_nms_xb_scatter: boxes into x-bucket order (bbox = corners, bar = {area, rank});
 //   k_nms_band    : the pair search;
-//   k_nms_resolve_fp: the greedy keep list as a fixed point instead of a serial chain (below).
+//   k_nms_resolve_mc: the greedy keep list as a fixed point instead of a serial chain (below).
 #define XB_G 4096
 #define BAND_STAGE 256
 __device__ __forceinline__ int xb_bucket(float x, float xmin, float scale)
@@ -1226,7 +1250,7 @@ __device__ __forceinline__ int xb_bucket(float x, float xmin, float scale)
 __global__ __launch_bounds__(1024) void k_nms_xbucket(const float *__restrict__ sx1, const float *__restrict__ sx2,
                                                       const float *__restrict__ sarea, const int32_t *__restrict__ counts,
                                                       int64_t nmax, int64_t Np, int force, NmsHdr *__restrict__ hdr,
-                                                      int32_t *__restrict__ start, int32_t *__restrict__ pos)
+                                                      int32_t *__restrict__ start, int32_t *__restrict__ pos, int32_t *__restrict__ lcnt)
 {
     __shared__ int s_hist[XB_G];
     __shared__ int s_start[XB_G + 1];
@@ -1237,6 +1261,7 @@ __global__ __launch_bounds__(1024) void k_nms_xbucket(const float *__restrict__ 
     const int n = counts ? counts[img] : (int)nmax;
     const int64_t o = (int64_t)img * Np;
     NmsHdr *h = hdr + img;
+    if (tid < 64) lcnt[(img * 64 + tid) * LC_STRIDE] = 0;                       // the image's pair lists start empty
     float mn = INFINITY, mx = -INFINITY;
     int bad = 0;
     // a thread's boxes: the 16-byte chunks tid, tid + 1024, ... (four boxes each, at most 16 chunks), eight chunk loads in flight
@@ -1268,7 +1293,7 @@ __global__ __launch_bounds__(1024) void k_nms_xbucket(const float *__restrict__ 
 #pragma unroll
     for (int k = 0; k < 16; ++k) { mn = fminf(mn, s_mn[k]); mx = fmaxf(mx, s_mx[k]); bad |= s_bad[k]; }
     if (bad || force == 0 || n <= 64) {                           // uniform
-        if (tid == 0) { h->xmin = 0.f; h->scale = 0.f; h->mode = 1; h->fpdone = 0; h->rounds = 0; h->npairs = 0; }
+        if (tid == 0) { h->xmin = 0.f; h->scale = 0.f; h->mode = 1; h->fpdone = 0; h->rounds = 0; h->npairs = 0; h->cpb = 0; h->estsum = 0u; }
         return;
     }
     const float range = mx - mn;
@@ -1345,8 +1370,9 @@ __global__ __launch_bounds__(1024) void k_nms_xbucket(const float *__restrict__ 
     if (tid == 0) {
         // candidates per box ~ s_cand / 1024; the band kernel tests about 1.8 x as many pairs (a row tile runs to the end of
         // its widest box), the dense mask n / 2 per box
-        const bool prune = force == 2 || s_cand * 8ull <= 1024ull * (unsigned long long)n;
+        const bool prune = force == 2 || s_cand * 4ull <= 1024ull * (unsigned long long)n;
         h->xmin = mn; h->scale = scale; h->mode = prune ? 0 : 1; h->fpdone = 0; h->rounds = 0; h->npairs = 0;
+        h->cpb = (int32_t)(s_cand >> 10); h->estsum = 0u;
     }
 }
 
@@ -1374,10 +1400,50 @@ __global__ __launch_bounds__(256) void k_nms_xb_scatter(const float *__restrict_
 }
 
 // the mask phase on its own (dg_nms_phase_mask called again on a sorted workspace, as bench.py times it): the pair list starts empty
-__global__ void k_nms_reset_pairs(NmsHdr *__restrict__ hdr, int batch)
+__global__ void k_nms_reset_pairs(NmsHdr *__restrict__ hdr, int32_t *__restrict__ lcnt, int batch)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < batch) hdr[i].npairs = 0;
+    if (i < batch * 64) lcnt[i * LC_STRIDE] = 0;
+    if (i < batch) { hdr[i].npairs = 0; hdr[i].estsum = 0u; }
+}
+
+// How many suppressing pairs will the band search find?  Known only once the threshold is: 1024 boxes spread over the x-bucket
+// order, each against 64 of its candidates (all of them if it has no more), scaled up.  A dense set at a low threshold has
+// hundreds of pairs per box -- writing and resolving them costs more than the dense mask does (27 M pairs for the dense
+// 64 k set at 0.3: 5 ms against 1.9) -- so above NMS_EST_MAX / 1024 pairs per box k_nms_band leaves the image to the dense path.
+#define NMS_EST_MAX (128u * 1024u)
+__global__ __launch_bounds__(256) void k_nms_estimate(const float4 *__restrict__ bbox, const float2 *__restrict__ bar,
+                                                      NmsHdr *__restrict__ hdr, const int32_t *__restrict__ counts, int64_t nmax,
+                                                      int64_t Np, float thr)
+{
+    const int img = blockIdx.y;
+    NmsHdr *h = hdr + img;
+    if (h->mode != 0) return;
+    const int n = counts ? counts[img] : (int)nmax;
+    const int64_t o = (int64_t)img * Np;
+    const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6);      // 1024 waves per image, one sample each
+    u32 sum = 0;
+    {
+        const int p = (int)(((long long)gw * n) >> 10);
+        const float4 b = bbox[o + p];
+        const float2 ar = bar[o + p];
+        int e = (int)(((u32)__float_as_int(ar.y) >> 16) + 1) * 64;
+        e = e < n ? e : n;
+        const int cand = e - (p + 1);
+        if (cand <= 0) return;                                     // wave-uniform
+        const int q = p + 1 + (cand <= 64 ? lane : (int)(((long long)lane * cand) >> 6));
+        bool hit = false;
+        if (cand > 64 || lane < cand) {
+            const float4 c = bbox[o + q];
+            const float ca = bar[o + q].x;
+            const float ix = fmaxf(fminf(b.z, c.z) - fmaxf(b.x, c.x), 0.0f), iy = fmaxf(fminf(b.w, c.w) - fmaxf(b.y, c.y), 0.0f);
+            const float inter = ix * iy, den = ((ar.x + ca) - inter) + 1e-7f;
+            hit = !(inter < thr * den);
+        }
+        const u32 c = (u32)__builtin_popcountll(__ballot(hit));
+        sum += cand <= 64 ? c : (u32)(((unsigned long long)c * (unsigned)cand) >> 6);
+    }
+    if (lane == 0 && sum) atomicAdd(&h->estsum, sum);
 }
 
 __global__ void k_nms_force_dense(NmsHdr *__restrict__ hdr, int batch)
@@ -1393,21 +1459,28 @@ template <bool TIE_EVEN>
 __global__ __launch_bounds__(256, 4) void k_nms_band(const float4 *__restrict__ bbox, const float2 *__restrict__ bar,
                                                      const int32_t *__restrict__ start, NmsHdr *__restrict__ hdr,
                                                      const int32_t *__restrict__ counts, int64_t nmax, int64_t Np,
-                                                     int64_t ecap, float thr, float thr_below, double mid, u32 *__restrict__ elist)
+                                                     int64_t lcap, int lsh, float thr, float thr_below, double mid,
+                                                     u64 *__restrict__ maskws, int64_t W, int32_t *__restrict__ lcnt, int force)
 {
     __shared__ float4 rbox[64];
     __shared__ float rarea[64];
     __shared__ int rrank[64];
     __shared__ int s_jend;
-    __shared__ u32 s_stage[4][BAND_STAGE];                         // a wave's pairs wait here: one bump of the list cursor per flush
+    __shared__ u32 s_stage[4][BAND_STAGE];                         // a wave's pairs wait here: one bump of the list cursors per flush
+    __shared__ int s_ocnt[4][64], s_obase[4][64];
     const int img = blockIdx.z;
     NmsHdr *h = hdr + img;
     if (h->mode != 0) return;
+    if (force != 2 && h->estsum > NMS_EST_MAX) {                   // too many pairs to list (k_nms_estimate): the dense path does this image
+        if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *(volatile int32_t *)&h->mode = 1;
+        return;
+    }
     const int n = counts ? counts[img] : (int)nmax;
     const int t = blockIdx.y;
     if (t * 64 >= n) return;
     const int64_t o = (int64_t)img * Np;
-    elist += (int64_t)img * (ecap + CSR_SLACK);
+    u32 *lists = (u32 *)(maskws + (int64_t)img * Np * W);           // list g: lists + g * lcap
+    lcnt += img * 64 * LC_STRIDE;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid < 64) {
         const float4 b = bbox[o + t * 64 + tid];
@@ -1423,16 +1496,36 @@ __global__ __launch_bounds__(256, 4) void k_nms_band(const float4 *__restrict__ 
     const float2 *cbar = bar + o;
     u32 *stage = s_stage[wave];
     int staged = 0;                                                // wave-uniform
+    // the staged pairs go to the list of their higher rank's owner (64 lists: k_nms_resolve_mc gives each to one workgroup):
+    // counted per list in LDS, one bump of each touched list's cursor, then every pair to its slot
+    int *oc = s_ocnt[wave], *ob = s_obase[wave];
     auto flush = [&]() {
         if (staged == 0) return;
-        int base = 0;
-        if (lane == 0) {
-            base = atomicAdd(&h->npairs, staged);
-            if ((int64_t)base + staged > ecap) *(volatile int32_t *)&h->mode = 1;      // list full: the dense path redoes this image
+        oc[lane] = 0;
+        u32 key[4];
+        int loc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = lane + 64 * q;
+            key[q] = 0u; loc[q] = 0;
+            if (i < staged) { key[q] = stage[i]; loc[q] = atomicAdd(&oc[(key[q] & 0xffffu) >> lsh], 1); }
         }
-        base = __shfl(base, 0, 64);
-        for (int i = lane; i < staged; i += 64)
-            if (base + i < ecap) elist[base + i] = stage[i];
+        const int c = oc[lane];
+        int b = 0;
+        if (c) {
+            b = atomicAdd(&lcnt[lane * LC_STRIDE], c);
+            if ((int64_t)b + c > lcap) *(volatile int32_t *)&h->mode = 1;        // a list is full: the dense path redoes this image
+        }
+        ob[lane] = b;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int i = lane + 64 * q;
+            if (i < staged) {
+                const int own = (int)((key[q] & 0xffffu) >> lsh);
+                const int64_t at = (int64_t)ob[own] + loc[q];
+                if (at < lcap) lists[(int64_t)own * lcap + at] = key[q];
+            }
+        }
         staged = 0;
     };
 #pragma unroll 1
@@ -1473,188 +1566,215 @@ __global__ __launch_bounds__(256, 4) void k_nms_band(const float4 *__restrict__ 
         }
         if (j == t) myword &= ~((2ull << lane) - 1ull);            // later positions only: every pair once
         const int cnt = __builtin_popcountll(myword);
-        if (__ballot(cnt != 0)) {                                  // wave-uniform: one cursor bump for the wave's pairs
+        if (__ballot(cnt != 0)) {                                  // wave-uniform
             int incl = cnt;
 #pragma unroll
             for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
             const int total = __shfl(incl, 63, 64);
-            const bool direct = total > BAND_STAGE;                // a tile of near-duplicates: straight to the list
-            if (!direct && staged + total > BAND_STAGE) flush();
-            int base = 0;
-            if (direct) {
-                if (lane == 0) {
-                    base = atomicAdd(&h->npairs, total);
-                    if ((int64_t)base + total > ecap) *(volatile int32_t *)&h->mode = 1;
-                }
-                base = __shfl(base, 0, 64);
-            }
-            int at = (direct ? base : staged) + incl - cnt;
-            if (myword) {
-                const int rr = rrank[lane];
+            const int rr = rrank[lane];
+            auto key_of = [&](int c) {
+                const int cr = __float_as_int(cbar[(int64_t)j * 64 + c].y) & 0xffff;
+                const u32 lo = (u32)(rr < cr ? rr : cr), hi = (u32)(rr < cr ? cr : rr);
+                return (lo << 16) | hi;                            // ranks < 65536 (W <= 1024)
+            };
+            if (total <= BAND_STAGE) {
+                if (staged + total > BAND_STAGE) flush();
+                int at = staged + incl - cnt;
                 while (myword) {
                     const int c = __builtin_ctzll(myword);
                     myword &= myword - 1;
-                    const int cr = __float_as_int(cbar[(int64_t)j * 64 + c].y) & 0xffff;
-                    const u32 lo = (u32)(rr < cr ? rr : cr), hi = (u32)(rr < cr ? cr : rr);
-                    const u32 key = (lo << 16) | hi;               // ranks < 65536 (W <= 1024)
-                    if (direct) { if (at < ecap) elist[at] = key; }
-                    else stage[at] = key;
-                    ++at;
+                    stage[at++] = key_of(c);
+                }
+                staged += total;
+            } else {                                               // a tile of near-duplicates: four pairs per row at a time
+                flush();
+                while (__ballot(myword != 0ull)) {
+                    const int pc = __builtin_popcountll(myword), c4 = pc < 4 ? pc : 4;
+                    int in2 = c4;
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(in2, d, 64); if (lane >= d) in2 += up; }
+                    int at = in2 - c4;
+                    for (int q = 0; q < c4; ++q) {
+                        const int c = __builtin_ctzll(myword);
+                        myword &= myword - 1;
+                        stage[at++] = key_of(c);
+                    }
+                    staged = __shfl(in2, 63, 64);
+                    flush();
                 }
             }
-            if (!direct) staged += total;
         }
     }
     flush();
 }
 
 // The keep list as a FIXED POINT instead of a chain over 64-row blocks.  A box is kept iff no kept box of higher rank
-// suppresses it; with the suppressing pairs as a list of entries (source row, target word, bits) that unfolds in rounds:
-//   an entry whose source is KEPT marks its targets REMOVED and dies; one whose source is REMOVED dies; one whose source is
-//   still undecided blocks its targets for this round; after the pass every undecided box that nothing blocks is KEPT.
+// suppresses it; with the suppressing pairs as a list of entries (source rank, target rank) that unfolds in rounds:
+//   an entry whose source is KEPT marks its target REMOVED and dies; one whose source is REMOVED dies; one whose source is
+//   still undecided blocks its target for this round; after the pass every undecided box that nothing blocks is KEPT.
 // The highest-ranked undecided box is decided in every round, so it ends; with scores independent of geometry the number of
-// rounds grows like log^2 n (parallel greedy MIS), about ten for config 5.  One 1024-thread workgroup per image, the four bit
-// sets in LDS, the live entries in a work list that shrinks every round.  After `max_rounds` (or a full work list) it gives
-// up and k_nms_reduce_csr<SEG> walks the segments serially instead (a chain of n boxes each suppressing the next would
-// need n rounds).  R2 = targets marked by at least two kept sources: the reference's `numel()>1` quirk (yolo.py:196) drops
-// the last kept box iff every lower-ranked box was already removed by OTHER kept boxes, i.e. iff no target of its own
-// entries has only it as kept suppressor.
-__global__ __launch_bounds__(1024) void k_nms_resolve_fp(NmsHdr *__restrict__ hdr, const int32_t *__restrict__ counts, int64_t nmax,
-                                                         int64_t Np, int64_t W, int64_t ecap, const u32 *__restrict__ elist,
-                                                         const int32_t *__restrict__ order, u64 *__restrict__ maskws, int max_rounds,
-                                                         int quirk, int64_t *__restrict__ keep, int32_t *__restrict__ keep_count)
+// rounds grows like log^2 n (parallel greedy MIS), about ten for config 5.
+// MC_G = 64 workgroups per image.  Workgroup g owns the targets g << lsh .. and their pair list (k_nms_band put every pair
+// into its higher rank's list): the targets' KEPT / REMOVED / R2 / blocked bits live in ITS LDS and only it touches them; what
+// a round needs from the others is the state of the SOURCES, a snapshot of all KEPT and REMOVED words that every workgroup
+// publishes (its own words) before the round's grid barrier and reads (all words) after it.  A snapshot that is one round old
+// is harmless: KEPT / REMOVED bits are final once set, and a source that still looks undecided only keeps its entry alive for
+// another round.  One barrier per round (a round costs about 10 us: four dependent trips to memory): a 64-bit word per round
+// that every workgroup adds (its live entries << 8 | 1) to and spins on until 64 have arrived -- bounded: a barrier nobody
+// releases ends the kernel with keep_count = -1 instead of hanging it.  All 64 workgroups of an image are dispatched before any
+// of the next image, so the ones that spin never wait for one that has not started.  Everything the workgroups tell each
+// other goes through agent-scope atomic loads and stores (the XCDs' L2s are not coherent with each other for plain
+// accesses); each publisher waits for its stores before the workgroup's arrival is counted.  (One workgroup with every bit
+// set in its LDS and no barrier was measured too: 141 us for config 5's 103 k pairs against 92 us, 610 against 125 for
+// 625 k pairs; only below about 10 k pairs was it the faster one, 28 against 47 us.)
+// Thread t owns the 16-byte chunks t, t + 1024, ... of its workgroup's list (four entries each); the entries that stay live
+// it writes back to the same chunks of the work list, in order (in place from the second pass on: the write index never
+// passes the read index), so no cursor, no atomics on memory, coalesced accesses and 32 entries in flight per thread.  The
+// sources' states of 16 entries are read together (one LDS round trip instead of 16).
+// The reference's `numel()>1` quirk (yolo.py:196) drops the last kept box iff every lower-ranked box was already removed by
+// OTHER kept boxes, i.e. iff no removed box has it as its ONLY kept suppressor: R2 = targets marked by at least two kept
+// sources, single[t] = the first kept source that marked t; the box is dropped iff the highest single[] among the removed
+// targets outside R2 is not the last kept box.
+// After `max_rounds` it gives up and k_nms_reduce_csr<SEG> walks the pairs serially instead (a chain of n boxes each
+// suppressing the next would need n rounds) -- unless the pairs are more than that kernel's lists hold: then the rounds
+// simply go on (n of them at the very worst).
+#define MC_G 64
+#define MC_K 0            // 2048 words: kept bits
+#define MC_R 2048         // 2048 words: removed bits
+#define MC_SLOT 4096      // 3 x u64: round r's arrivals (low 8 bits) and live entries (the rest) in slot r % 3
+#define MC_KCNT 4104      // 64: kept boxes of each workgroup's targets
+#define MC_KMAX 4168      // 64: highest kept rank + 1
+#define MC_SNGL 4232      // 64: highest sole suppressor + 1
+#define MC_WORDS 4352
+#define MC_SPIN_LIMIT (1u << 21)
+__device__ __forceinline__ u32 mc_ld(const u32 *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void mc_st(u32 *p, u32 v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ u32 nms_valid32(int w, int n)
 {
-    // the bit sets as 32-bit words (32-bit shifts and LDS atomics); KEPT and REMOVED interleaved -- KR[2w] = kept bits of
-    // boxes 32w .. 32w+31, KR[2w+1] = removed bits -- so that a source's state is one 8-byte LDS read
-    __shared__ __attribute__((aligned(16))) u32 KR[4096];
-    __shared__ u32 R2[2048], Bk[2048];
-    __shared__ int s_off[1024];
-    __shared__ int s_last, s_part[16], s_live[2], s_cursor;
-    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int vb = w * 32;
+    return (vb >= n) ? 0u : ((n - vb >= 32) ? ~0u : ((1u << (n - vb)) - 1u));
+}
+
+struct NmsFpShared {
+    __attribute__((aligned(16))) u32 KR[4096];   // the sources' states: KR[2w] = kept bits of boxes 32w .. 32w+31, KR[2w+1] = removed bits
+    u32 oK[32], oR[32], oR2[32], oBk[32];         // the targets this workgroup owns (1 << lsh <= 1024 of them)
+    unsigned short single[1024];                  // first kept suppressor of each owned target
+    int off[32];
+    int cnt[16], ok, sngl;
+    unsigned long long live;
+};
+
+__global__ __launch_bounds__(1024) void k_nms_resolve_mc(NmsHdr *__restrict__ hdr, const int32_t *__restrict__ counts, int64_t nmax,
+                                                         int64_t Np, int64_t W, int64_t lcap, int lsh, int64_t ecap,
+                                                         const int32_t *__restrict__ lcnt, const int32_t *__restrict__ order,
+                                                         u64 *__restrict__ maskws, u32 *__restrict__ mc, int max_rounds, int quirk,
+                                                         int64_t *__restrict__ keep, int32_t *__restrict__ keep_count)
+{
+    __shared__ NmsFpShared S;
+    const int img = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     NmsHdr *h = hdr + img;
-    if (h->mode != 0) return;
+    lcnt += img * 64 * LC_STRIDE;
+    int Etot = lcnt[lane * LC_STRIDE];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) Etot += __shfl_xor(Etot, d, 64);
+    if (h->mode != 0) {                                          // dense mask; if a pair list overflowed, say how many pairs there were
+        if (g == 0 && tid == 0) h->npairs = Etot;
+        return;
+    }
     const int n = counts ? counts[img] : (int)nmax;
-    const int nb = (n + 63) >> 6;
-    const int E = h->npairs;                                     // <= ecap (mode would be 1 otherwise)
-    elist += (int64_t)img * (ecap + CSR_SLACK);
     order += (int64_t)img * Np;
     keep += (int64_t)img * nmax;
-    u32 *wlist = (u32 *)(maskws + (int64_t)img * Np * W);        // the work list (ecap entries) lives in this image's unused dense mask
+    u32 *mcs = mc + (int64_t)img * MC_WORDS;
+    const u32 *list = (const u32 *)(maskws + (int64_t)img * Np * W) + (int64_t)g * lcap;       // 64 pair lists, then the 64 work lists
+    u32 *wlist = (u32 *)(maskws + (int64_t)img * Np * W) + (int64_t)(MC_G + g) * lcap;
     u32 *wmine = wlist + 4 * tid;
-    u32 valid32[2];                                              // of the 32-bit words 2 tid, 2 tid + 1
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int vb = (2 * tid + q) * 32;
-        valid32[q] = (vb >= n) ? 0u : ((n - vb >= 32) ? ~0u : ((1u << (n - vb)) - 1u));
-    }
-#pragma unroll
-    for (int q = 0; q < 4; ++q) KR[4 * tid + q] = 0u;
-    R2[2 * tid] = 0u; R2[2 * tid + 1] = 0u; Bk[2 * tid] = 0u; Bk[2 * tid + 1] = 0u;
-    if (tid == 0) { s_last = -1; s_part[0] = 0; s_live[0] = 0; s_live[1] = 0; s_cursor = 0; }
-    // `order` is read at the very end, 64 dependent-free words per lane but from memory no cache of this CU's XCD holds (a
-    // round trip of about 2.4 us for this lone workgroup): one word of each of its 128-byte lines is loaded now, which
-    // brings the lines into the L2 the final loads will hit
-    const int pf0 = (tid * 32 < nb * 64) ? order[tid * 32] : 0, pf1 = ((tid + 1024) * 32 < nb * 64) ? order[(tid + 1024) * 32] : 0;
+    const int E = lcnt[g * LC_STRIDE];                           // <= lcap (mode would be 1 otherwise)
+    const int own0 = g << lsh, ow0 = own0 >> 5, nown = (1 << lsh) >> 5;
+    if (tid < 32) { S.oK[tid] = 0u; S.oR[tid] = 0u; S.oR2[tid] = 0u; S.oBk[tid] = 0u; }
     __syncthreads();
-#ifdef DG_FP_STAMPS
-    if (tid == 0) ((long long *)(wlist + ecap))[61] = wall_clock64();
-#endif
     // round 0: boxes nothing suppresses are kept
     for (int64_t c0 = 0; c0 * 4 < E; c0 += 8 * 1024) {
         uint4 v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int64_t c = c0 + u * 1024 + tid;
-            v[u] = (c * 4 < E) ? *(const uint4 *)(elist + 4 * c) : make_uint4(0, 0, 0, 0);
+            v[u] = (c * 4 < E) ? *(const uint4 *)(list + 4 * c) : make_uint4(0, 0, 0, 0);
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int64_t e = (c0 + u * 1024 + tid) * 4;
-            if (e < E) atomicOr(&Bk[(v[u].x & 0xffffu) >> 5], 1u << (v[u].x & 31u));
-            if (e + 1 < E) atomicOr(&Bk[(v[u].y & 0xffffu) >> 5], 1u << (v[u].y & 31u));
-            if (e + 2 < E) atomicOr(&Bk[(v[u].z & 0xffffu) >> 5], 1u << (v[u].z & 31u));
-            if (e + 3 < E) atomicOr(&Bk[(v[u].w & 0xffffu) >> 5], 1u << (v[u].w & 31u));
+            if (e < E) atomicOr(&S.oBk[((v[u].x & 0xffffu) >> 5) - ow0], 1u << (v[u].x & 31u));
+            if (e + 1 < E) atomicOr(&S.oBk[((v[u].y & 0xffffu) >> 5) - ow0], 1u << (v[u].y & 31u));
+            if (e + 2 < E) atomicOr(&S.oBk[((v[u].z & 0xffffu) >> 5) - ow0], 1u << (v[u].z & 31u));
+            if (e + 3 < E) atomicOr(&S.oBk[((v[u].w & 0xffffu) >> 5) - ow0], 1u << (v[u].w & 31u));
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int q = 0; q < 2; ++q) { KR[2 * (2 * tid + q)] = valid32[q] & ~Bk[2 * tid + q]; Bk[2 * tid + q] = 0u; }
-    // Thread t owns the 16-byte chunks t, t + 1024, t + 2048, ... of the pair list (four entries each); the entries that
-    // stay live it writes back to the same chunks of the work list, in order (in place from the second round on: the write
-    // index never passes the read index), so no cursor, no atomics on memory, coalesced accesses and 32 entries in flight
-    // per thread.  One entry: its source is KEPT -> mark the target REMOVED (and R2 if it already was), dead; REMOVED ->
-    // dead; undecided -> block the target for this round, live.  The sources' states of 16 entries are read together (one
-    // LDS round trip instead of 16; a REMOVED bit set meanwhile only costs the entry one more round).  For the quirk every
-    // thread remembers the targets of the highest-ranked kept source it applied (the last kept box, if it has entries at
-    // all, is that for some thread).
-    const u32 *src_list = elist;
+    if (tid < 32) { S.oK[tid] = (tid < nown ? nms_valid32(ow0 + tid, n) : 0u) & ~S.oBk[tid]; S.oBk[tid] = 0u; }
+    const u32 *src_list = list;
     int mycnt = 0;
     for (int64_t c = tid; c * 4 < E; c += 1024) mycnt += (E - c * 4 >= 4) ? 4 : (int)(E - c * 4);
-    int rounds = 0, bsrc = -1, bn = 0;
-    u64 bpack = 0;
-    bool bail = false;
-#ifdef DG_FP_STAMPS
-    long long *dbg = (long long *)(wlist + ecap);
-    if (tid == 0) { dbg[0] = wall_clock64(); }
-#endif
+    int rounds = 0;
+    bool bail = false, hung = false;
     for (;;) {
-#ifdef DG_FP_STAMPS
+        __syncthreads();
         {
             int c = mycnt;
-            for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
-            if (lane == 0) atomicAdd(&s_part[0], c);
-            __syncthreads();
-            if (tid == 0 && rounds < 30) { dbg[1 + 2 * rounds] = wall_clock64(); dbg[2 + 2 * rounds] = s_part[0]; s_part[0] = 0; }
-            __syncthreads();
-        }
-#endif
-        {   // live entries in all: none -> every box is decided; a handful -> the register-held rounds below
-            int c = mycnt;
 #pragma unroll
             for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
-            if (lane == 0 && c) atomicAdd(&s_live[rounds & 1], c);
-            if (tid == 0) s_live[(rounds + 1) & 1] = 0;
-            __syncthreads();
+            if (lane == 0) S.cnt[wave] = c;
+            if (tid == 0) S.sngl = 0;
         }
-        const int live = s_live[rounds & 1];
-        if (live == 0) break;
-        if (rounds >= max_rounds) { bail = true; break; }
-        if (live <= 1024) {
-            // few entries left: one per thread, held in a register -- a round is two barriers and no memory traffic
-            int *small = s_off;                                  // (free until the keep list is written)
-            for (int p = 0; p < mycnt; ++p) small[atomicAdd(&s_cursor, 1)] = (int)src_list[4 * (tid + 1024 * (p >> 2)) + (p & 3)];
-            __syncthreads();
-            const u32 key = tid < live ? (u32)small[tid] : 0u;
-            const u32 src = key >> 16, dst = key & 0xffffu, sb = 1u << (src & 31), db = 1u << (dst & 31);
-            bool alive = tid < live;
-            for (;;) {
-                if (!__syncthreads_or(alive)) break;
-                if (rounds >= max_rounds) { bail = true; break; }
-                if (alive) {
-                    const uint2 kr = *(const uint2 *)&KR[2 * (src >> 5)];
-                    if (kr.x & sb) {
-                        const u32 old = atomicOr(&KR[2 * (dst >> 5) + 1], db);
-                        if (old & db) atomicOr(&R2[dst >> 5], db);
-                        if ((int)src > bsrc) { bsrc = (int)src; bn = 0; }
-                        if ((int)src == bsrc) { bpack = (bpack << 16) | dst; ++bn; }
-                        alive = false;
-                    } else if (kr.y & sb) {
-                        alive = false;
-                    } else {
-                        atomicOr(&Bk[dst >> 5], db);
-                    }
-                }
-                __syncthreads();
+        __syncthreads();
+        // ---- publish: this workgroup's words, its kept count / highest kept rank / highest sole suppressor
+        {
+            int v = 0;                                             // one owned target per thread
+            if (tid < (1 << lsh) && ((S.oR[tid >> 5] & ~S.oR2[tid >> 5]) >> (tid & 31)) & 1u) v = (int)S.single[tid] + 1;
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int w = 2 * tid + q;
-                    KR[2 * w] |= valid32[q] & ~(KR[2 * w] | KR[2 * w + 1] | Bk[w]);
-                    Bk[w] = 0u;
-                }
-                ++rounds;
+            for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
+            if (lane == 0 && v) atomicMax(&S.sngl, v);
+        }
+        __syncthreads();
+        if (tid < nown) { mc_st(&mcs[MC_K + ow0 + tid], S.oK[tid]); mc_st(&mcs[MC_R + ow0 + tid], S.oR[tid]); }
+        if (wave == 1) {
+            const u32 kw = lane < nown ? S.oK[lane] : 0u;
+            int kc = __builtin_popcount(kw), km = kw ? (ow0 + lane) * 32 + 32 - __builtin_clz(kw) : 0;
+#pragma unroll
+            for (int d = 32; d > 0; d >>= 1) { kc += __shfl_xor(kc, d, 64); km = max(km, __shfl_xor(km, d, 64)); }
+            if (lane == 0) {
+                mc_st(&mcs[MC_KCNT + g], (u32)kc); mc_st(&mcs[MC_KMAX + g], (u32)km); mc_st(&mcs[MC_SNGL + g], (u32)S.sngl);
+                if (g == 0)                                        // next round's slot: last read two barriers ago
+                    __hip_atomic_store((unsigned long long *)&mcs[MC_SLOT + 2 * ((rounds + 1) % 3)], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            break;
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");           // what this thread published has arrived
+        __syncthreads();
+        // ---- grid barrier `rounds`
+        if (tid == 0) {
+            unsigned long long mine = 1ull;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) mine += (unsigned long long)S.cnt[k] << 8;
+            unsigned long long *slot = (unsigned long long *)&mcs[MC_SLOT + 2 * (rounds % 3)];
+            atomicAdd(slot, mine);
+            u32 spins = 0;
+            int ok = 1;
+            unsigned long long v;
+            while (((v = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xffull) < (unsigned long long)MC_G) {
+                __builtin_amdgcn_s_sleep(1);
+                if (++spins > MC_SPIN_LIMIT) { ok = 0; break; }
+            }
+            S.ok = ok; S.live = v >> 8;
+        }
+        __syncthreads();
+        if (!S.ok) { hung = true; break; }
+        if (S.live == 0ull) break;                                 // every box is decided
+        if (rounds >= max_rounds && Etot <= ecap) { bail = true; break; }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int w = tid + 1024 * q;
+            if (w < 2 * (int)W) { S.KR[2 * w] = mc_ld(&mcs[MC_K + w]); S.KR[2 * w + 1] = mc_ld(&mcs[MC_R + w]); }
+        }
+        __syncthreads();
         int out = 0;
         const int nch = (mycnt + 3) >> 2;
         for (int c0 = 0; c0 < nch; c0 += 8) {
@@ -1670,7 +1790,7 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_fp(NmsHdr *__restrict__ hd
                 for (int i = 0; i < 16; ++i) {
                     const uint4 vv = v[hh * 4 + (i >> 2)];
                     key[i] = (i & 3) == 0 ? vv.x : ((i & 3) == 1 ? vv.y : ((i & 3) == 2 ? vv.z : vv.w));
-                    kr[i] = *(const uint2 *)&KR[2 * (key[i] >> 21)];
+                    kr[i] = *(const uint2 *)&S.KR[2 * (key[i] >> 21)];
                 }
                 u32 old[16];                                     // the returning atomics of all 16 issued before the first is waited for
                 u32 applied = 0;
@@ -1678,13 +1798,13 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_fp(NmsHdr *__restrict__ hd
                 for (int i = 0; i < 16; ++i) {
                     old[i] = 0u;
                     if ((c0 + hh * 4) * 4 + i >= mycnt) continue;
-                    const u32 src = key[i] >> 16, dst = key[i] & 0xffffu;
+                    const u32 src = key[i] >> 16, dst = (key[i] & 0xffffu) - (u32)own0;
                     const u32 sb = 1u << (src & 31), db = 1u << (dst & 31);
                     if (kr[i].x & sb) {
-                        old[i] = atomicOr(&KR[2 * (dst >> 5) + 1], db);
+                        old[i] = atomicOr(&S.oR[dst >> 5], db);
                         applied |= 1u << i;
                     } else if (!(kr[i].y & sb)) {
-                        atomicOr(&Bk[dst >> 5], db);
+                        atomicOr(&S.oBk[dst >> 5], db);
                         wmine[((out >> 2) << 12) + (out & 3)] = key[i];
                         ++out;
                     }
@@ -1693,11 +1813,9 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_fp(NmsHdr *__restrict__ hd
 #pragma unroll
                     for (int i = 0; i < 16; ++i) {
                         if (!((applied >> i) & 1u)) continue;
-                        const int src = (int)(key[i] >> 16);
-                        const u32 dst = key[i] & 0xffffu, db = 1u << (dst & 31);
-                        if (old[i] & db) atomicOr(&R2[dst >> 5], db);
-                        if (src > bsrc) { bsrc = src; bn = 0; }
-                        if (src == bsrc) { bpack = (bpack << 16) | dst; ++bn; }
+                        const u32 dst = (key[i] & 0xffffu) - (u32)own0, db = 1u << (dst & 31);
+                        if (old[i] & db) atomicOr(&S.oR2[dst >> 5], db);
+                        else S.single[dst] = (unsigned short)(key[i] >> 16);
                     }
                 }
             }
@@ -1705,76 +1823,51 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_fp(NmsHdr *__restrict__ hd
         mycnt = out;
         src_list = wlist;
         __syncthreads();
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {                            // what nothing blocks is kept
-            const int w = 2 * tid + q;
-            KR[2 * w] |= valid32[q] & ~(KR[2 * w] | KR[2 * w + 1] | Bk[w]);
-            Bk[w] = 0u;
+        if (tid < 32) {                                            // what nothing blocks is kept
+            S.oK[tid] |= (tid < nown ? nms_valid32(ow0 + tid, n) : 0u) & ~(S.oK[tid] | S.oR[tid] | S.oBk[tid]);
+            S.oBk[tid] = 0u;
         }
         ++rounds;
     }
-    if (bail) {                                                  // uniform: k_nms_reduce_csr<SEG> does this image from scratch
-        if (tid == 0) { h->fpdone = 0; h->rounds = rounds; }
+    if (hung) {                                                   // uniform within the workgroup; the others time out as well
+        if (tid == 0) {
+            if (Etot <= ecap) { h->fpdone = 0; }                  // the serial chain does this image
+            else { h->fpdone = 1; keep_count[img] = -1; }
+            h->rounds = -1; h->npairs = Etot;
+        }
         return;
     }
-#ifdef DG_FP_STAMPS
-    if (tid == 0) { dbg[63] = wall_clock64(); s_part[0] = 0; }
-    __syncthreads();
-#endif
-    // ---- the kept set is final: count, quirk, keep list in rank order
-    asm volatile("" ::"v"(pf0), "v"(pf1));                       // (the two prefetch loads of `order` end here)
-    const u64 kw = (u64)KR[4 * tid] | ((u64)KR[4 * tid + 2] << 32);      // kept bits of boxes 64 tid .. 64 tid + 63
-    const int mine = __builtin_popcountll(kw);
-    int incl = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
-    if (lane == 63) s_part[wave] = incl;
-    if (kw) atomicMax(&s_last, tid * 64 + 63 - __builtin_clzll(kw));
-    __syncthreads();
-    int base = 0, total = 0;
-    for (int k = 0; k < 16; ++k) { if (k < wave) base += s_part[k]; total += s_part[k]; }
-    s_off[tid] = base + incl - mine;                             // keep-list offset of 64-box word `tid`
-    const int km = s_last;
-    int drop = 0;
-    if (quirk && total > 0) {                                    // uniform
-        // the last kept box's own targets: from the threads that applied its entries; a thread that met more than four of
-        // them (a 64-bit pack) sends everybody through the whole list instead
-        const bool own = bsrc == km;
-        if (__syncthreads_or(own && bn > 4)) {
-            for (int e = tid; e < E; e += 1024) {
-                const u32 key = elist[e];
-                if ((int)(key >> 16) == km) atomicOr(&Bk[(key & 0xffffu) >> 5], 1u << (key & 31u));
-            }
-        } else if (own) {
-            for (int q = 0; q < bn; ++q) {
-                const u32 dst = (u32)(bpack >> (16 * q)) & 0xffffu;
-                atomicOr(&Bk[dst >> 5], 1u << (dst & 31u));
-            }
-        }
-        __syncthreads();
-        // none of them was left to it alone: nothing survived k1..k(m-1)
-        drop = !__syncthreads_or(((Bk[2 * tid] & ~R2[2 * tid]) | (Bk[2 * tid + 1] & ~R2[2 * tid + 1])) != 0u);
-    } else {
-        __syncthreads();
+    if (bail) {                                                   // uniform over the grid: k_nms_reduce_csr<SEG> does this image from scratch
+        if (g == 0 && tid == 0) { h->fpdone = 0; h->rounds = rounds; h->npairs = Etot; }
+        return;
     }
-    for (int w0 = wave; w0 < nb; w0 += 16 * 8) {                 // eight 64-box words per wave pass, their `order` loads in flight together
-        int ord[8];
+    // ---- the kept set is final and every workgroup's counts are out: keep list in rank order, each workgroup its targets
+    if (wave == 0) {
+        int kc = (int)mc_ld(&mcs[MC_KCNT + lane]), km = (int)mc_ld(&mcs[MC_KMAX + lane]), sg = (int)mc_ld(&mcs[MC_SNGL + lane]);
+        int incl = kc;
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { const int w = w0 + 16 * u; ord[u] = (w < nb) ? order[w * 64 + lane] : 0; }
+        for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int w = w0 + 16 * u;
-            if (w >= nb) continue;
-            u64 k = (u64)KR[4 * w] | ((u64)KR[4 * w + 2] << 32);
-            if (drop && w == (km >> 6)) k &= ~(1ull << (km & 63));
-            if ((k >> lane) & 1ull) keep[s_off[w] + __builtin_popcountll(k & ((1ull << lane) - 1ull))] = (int64_t)ord[u];
-        }
+        for (int d = 32; d > 0; d >>= 1) { km = max(km, __shfl_xor(km, d, 64)); sg = max(sg, __shfl_xor(sg, d, 64)); }
+        const int total = __shfl(incl, 63, 64), mybase = __shfl(incl - kc, g, 64);
+        const u32 kw = lane < nown ? S.oK[lane] : 0u;            // word offsets of this workgroup's kept bits
+        int wi = __builtin_popcount(kw);
+        const int wc = wi;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(wi, d, 64); if (lane >= d) wi += up; }
+        if (lane < 32) S.off[lane] = mybase + wi - wc;
+        if (lane == 0) { S.cnt[0] = total; S.cnt[1] = km; S.cnt[2] = sg; }
     }
-    if (tid == 0) { keep_count[img] = total - drop; h->fpdone = 1; h->rounds = rounds; }
-#ifdef DG_FP_STAMPS
     __syncthreads();
-    if (tid == 0) dbg[62] = wall_clock64();
-#endif
+    const int total = S.cnt[0], km = S.cnt[1] - 1;                 // km: the last kept box (-1: none)
+    const int drop = (quirk && total > 0 && S.cnt[2] - 1 != km) ? 1 : 0;
+    if (tid < (1 << lsh)) {
+        const int t = own0 + tid;
+        const u32 kw = S.oK[tid >> 5];
+        if (((kw >> (tid & 31)) & 1u) && !(drop && t == km))
+            keep[S.off[tid >> 5] + __builtin_popcount(kw & ((1u << (tid & 31)) - 1u))] = (int64_t)order[t];
+    }
+    if (g == 0 && tid == 0) { keep_count[img] = total - drop; h->fpdone = 1; h->rounds = rounds; h->npairs = Etot; }
 }
 
 // ---------------------------------------------------------------- host
@@ -1786,7 +1879,7 @@ extern "C" size_t dg_nms_workspace_bytes(int64_t batch, int64_t nmax)
 
 // DG_NMS_PRUNE: 0 = never take the pruned path, 1 (default) = where the candidate count says so, 2 = wherever it applies
 // (64 < W <= 1024, finite boxes, 2^-20 <= thr < inf), whatever the candidate count (tests).  DG_NMS_FP_ROUNDS: rounds after
-// which k_nms_resolve_fp hands over to the serial chain (default 128; 1 in tests sends every image there).
+// which k_nms_resolve_mc hands over to the serial chain (default 128; 1 in tests sends every image there).
 static int nms_prune_mode() { const char *e = getenv("DG_NMS_PRUNE"); return e ? atoi(e) : 1; }
 static int nms_fp_rounds() { const char *e = getenv("DG_NMS_FP_ROUNDS"); return e ? atoi(e) : 128; }
 
@@ -1846,7 +1939,7 @@ case 512: launch_sort_small<512>(w, boxes, scores, counts, batch, nmax, st); bre
     DG_CHECK_LAUNCH("nms sort");
     if (prune) {
         hipLaunchKernelGGL(k_nms_xbucket, dim3((unsigned)batch), dim3(1024), 0, st, w.x1, w.x2, w.area, counts, nmax, w.Np,
-                           nms_prune_mode(), w.hdr, w.start, w.pos);
+                           nms_prune_mode(), w.hdr, w.start, w.pos, w.lcnt);
         hipLaunchKernelGGL(k_nms_xb_scatter, dim3((unsigned)dg_cdiv(w.Np, 256), (unsigned)batch), dim3(256), 0, st, w.x1, w.y1, w.x2, w.y2,
                            w.area, w.pos, w.start, counts, nmax, w.hdr, w.Np, w.bbox, w.bar);
         DG_CHECK_LAUNCH("k_nms_xbucket");
@@ -1872,19 +1965,23 @@ static int nms_phase_mask(const int32_t *counts, int64_t batch, int64_t nmax, fl
     if (w.pruned && nms_prune_mode() != 0) {
         // the pruned pair search for the images k_nms_xbucket chose (hdr.mode == 0); the dense mask below runs for the others
         hdr = w.hdr;
-        if (standalone) hipLaunchKernelGGL(k_nms_reset_pairs, dim3((unsigned)dg_cdiv(batch, 256)), dim3(256), 0, (hipStream_t)s, w.hdr, (int)batch);
+        if (standalone) hipLaunchKernelGGL(k_nms_reset_pairs, dim3((unsigned)dg_cdiv(batch * 64, 256)), dim3(256), 0, (hipStream_t)s, w.hdr, w.lcnt, (int)batch);
         if (!fast_ok) {
             hipLaunchKernelGGL(k_nms_force_dense, dim3((unsigned)dg_cdiv(batch, 256)), dim3(256), 0, (hipStream_t)s, w.hdr, (int)batch);
         } else {
             unsigned parts = (unsigned)(w.W >= 1024 ? 2 : (w.W >= 512 ? 4 : 8));
             if (getenv("DG_NMS_BAND_PARTS")) parts = (unsigned)atoi(getenv("DG_NMS_BAND_PARTS"));
             const dim3 g(parts, (unsigned)w.W, (unsigned)batch);
+            const int force = nms_prune_mode();
+            if (force != 2)
+                hipLaunchKernelGGL(k_nms_estimate, dim3(256, (unsigned)batch), dim3(256), 0, (hipStream_t)s, w.bbox, w.bar, w.hdr, counts, nmax,
+                                   w.Np, threshold);
             if (tie_even)
                 hipLaunchKernelGGL((k_nms_band<true>), g, dim3(256), 0, (hipStream_t)s, w.bbox, w.bar, w.start, w.hdr, counts, nmax, w.Np,
-                                   w.ecap, threshold, below, mid, w.ekey);
+                                   w.lcap, w.lsh, threshold, below, mid, w.mask, w.W, w.lcnt, force);
             else
                 hipLaunchKernelGGL((k_nms_band<false>), g, dim3(256), 0, (hipStream_t)s, w.bbox, w.bar, w.start, w.hdr, counts, nmax, w.Np,
-                                   w.ecap, threshold, below, mid, w.ekey);
+                                   w.lcap, w.lsh, threshold, below, mid, w.mask, w.W, w.lcnt, force);
         }
         DG_CHECK_LAUNCH("k_nms_band");
     }
@@ -1920,12 +2017,13 @@ extern "C" int dg_nms_phase_reduce(const int32_t *counts, int64_t batch, int64_t
     const NmsHdr *hdr = nullptr;
     if (w.pruned && nms_prune_mode() != 0) {
         hdr = w.hdr;
-        hipLaunchKernelGGL(k_nms_resolve_fp, dim3((unsigned)batch), dim3(1024), 0, st, w.hdr, counts, nmax, w.Np, w.W, w.ecap, w.ekey,
-                           w.order, w.mask, nms_fp_rounds(), quirk_drop_last, keep, keep_count);
+        if (hipMemsetAsync(w.mc, 0, (size_t)batch * MC_WORDS * 4, st) != hipSuccess) { dg_set_error("nms_reduce: memset failed"); return DG_EHIP; }
+        hipLaunchKernelGGL(k_nms_resolve_mc, dim3(MC_G, (unsigned)batch), dim3(1024), 0, st, w.hdr, counts, nmax, w.Np, w.W, w.lcap, w.lsh,
+                           w.ecap, w.lcnt, w.order, w.mask, w.mc, nms_fp_rounds(), quirk_drop_last, keep, keep_count);
         hipLaunchKernelGGL(k_nms_reduce_csr<true>, dim3((unsigned)batch), dim3(1024), 0, st, w.mask, w.order, counts, nmax, w.Np,
                            w.W, w.ecap, (const int32_t *)nullptr, (const int32_t *)nullptr, w.ekey, w.eval, quirk_drop_last, keep, keep_count,
-                           w.hdr, w.diag);
-        DG_CHECK_LAUNCH("k_nms_resolve_fp");
+                           w.hdr, w.diag, w.lcnt, w.lcap);
+        DG_CHECK_LAUNCH("k_nms_resolve_mc");
     }
     if (w.W < NMS_CSR_MIN_W) RED(64, 1);
     else if (w.W <= 1024) {
@@ -1960,7 +2058,8 @@ extern "C" int dg_nms_phase_reduce(const int32_t *counts, int64_t batch, int64_t
             }
         }
         hipLaunchKernelGGL(k_nms_reduce_csr<false>, dim3((unsigned)batch), dim3(1024), 0, st, w.mask, w.order, counts, nmax, w.Np, w.W, w.ecap,
-                           w.cflag, w.boff, w.ekey, w.eval, quirk_drop_last, keep, keep_count, hdr, (const u64 *)nullptr);
+                           w.cflag, w.boff, w.ekey, w.eval, quirk_drop_last, keep, keep_count, hdr, (const u64 *)nullptr,
+                           (const int32_t *)nullptr, (int64_t)0);
         // images whose compact form overflowed (dense masks); returns at once for the others
         {
             const size_t lds = (size_t)w.W * 16 + (size_t)PIPE_ROWS * PIPE_NEAR * 8;      // removed, removed1, 64 KB band
@@ -1991,17 +2090,20 @@ extern "C" int dg_nms_batched_f32(const float *boxes, const float *scores, const
 
 // diagnostic: which path image `img` of the last call on this workspace took (synchronous; tests and bench.py use it to
 // make sure a timing or a parity claim is about the path it names)
-extern "C" int dg_nms_path_info(const void *ws, size_t ws_bytes, int64_t batch, int64_t nmax, int64_t img, int32_t *out4_host)
+extern "C" int dg_nms_path_info(const void *ws, size_t ws_bytes, int64_t batch, int64_t nmax, int64_t img, int32_t *out6_host)
 {
+    int32_t *out4_host = out6_host;
     DG_REQUIRE(out4_host && img >= 0 && img < batch, "nms_path_info: bad argument");
     NmsWs w;
     int rc = nms_check("nms_path_info", batch, nmax, (void *)ws, ws_bytes, &w);
     if (rc) return rc;
     out4_host[0] = 1; out4_host[1] = 0; out4_host[2] = 0; out4_host[3] = 0;        // dense mask, no fixed point
+    out6_host[4] = 0; out6_host[5] = 0;
     if (batch == 0 || nmax == 0 || !w.pruned || nms_prune_mode() == 0) return DG_OK;
     NmsHdr h;
     if (hipMemcpy(&h, w.hdr + img, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess) { dg_set_error("nms_path_info: copy failed"); return DG_EHIP; }
     out4_host[0] = h.mode; out4_host[1] = h.fpdone; out4_host[2] = h.rounds; out4_host[3] = h.npairs;
+    out6_host[4] = h.cpb; out6_host[5] = (int32_t)(h.estsum >> 10);               // candidates per box, estimated pairs per box
     return DG_OK;
 }
 

@@ -55,11 +55,12 @@ def nms_workspace(dev, batch, nmax):
 
 
 def nms_path_info(dev, batch, nmax, img=0):
-    """(mode, fpdone, rounds, npairs) of image `img` in the LAST NMS call that used this stream's workspace: mode 0 = pruned pair
-    search, 1 = dense mask; fpdone 1 = the fixed-point kernel produced the keep list.  Synchronous (diagnostic)."""
+    """(mode, fpdone, rounds, npairs, cand_per_box, est_pairs_per_box) of image `img` in the LAST NMS call that used this
+    stream's workspace: mode 0 = pruned pair search, 1 = dense mask; fpdone 1 = the fixed-point kernel produced the keep list.
+    Synchronous (diagnostic)."""
     import ctypes as C
     ws, nbytes = nms_workspace(dev, batch, nmax)
-    out = (C.c_int32 * 4)()
+    out = (C.c_int32 * 6)()
     with torch.cuda.device(dev):
         check(load().dg_nms_path_info(ptr(ws), nbytes, batch, nmax, img, out))
     return tuple(out)
