@@ -34,7 +34,7 @@ def test_shard_range_covers_everything():
 class OracleBackend:
     """test-only stand-in for cluster._HipBackend (same methods), stepping with oracle/oracle.c"""
 
-    def prepare(self, X, init_centers, k, iters):
+    def prepare(self, X, init_centers, k, iters, cells=None):
         from oracle import oracle as orc
         self.orc, self.k = orc, k
         self.wh = np.ascontiguousarray(X, np.float32)
