@@ -209,6 +209,87 @@ __global__ __launch_bounds__(256) void k_bitonic_global(u64 *__restrict__ keys, 
     if ((a > b) == asc) { g[i] = b; g[l] = a; }
 }
 
+// ---------------------------------------------------------------- sort, 4096 < n <= 65536: sorted chunks + rank merge
+// Two launches instead of the bitonic network's 17 (for 64 k keys about 100 us, most of it launch-to-launch): every
+// SORT_CHUNK of keys is built and sorted in LDS (ascending), then each key finds its final rank directly -- its place in its
+// own chunk plus, for every other chunk, the number of keys there that go before it (binary search: 6 steps over the chunk's
+// 64 block maxima in LDS, 6 inside one 64-key block in memory; equal keys -- the padding -- go by chunk order) -- and the
+// box is gathered straight to that rank.
+__global__ __launch_bounds__(1024) void k_nms_sort_chunks(const float *__restrict__ scores, const int32_t *__restrict__ counts,
+                                                          int64_t nmax, int64_t Np2, u64 *__restrict__ keys)
+{
+    __shared__ u64 s[SORT_CHUNK];
+    const int tid = threadIdx.x, img = blockIdx.y;
+    const int n = counts ? counts[img] : (int)nmax;
+    const int64_t base = (int64_t)blockIdx.x * SORT_CHUNK;
+    u64 *g = keys + (int64_t)img * Np2 + base;
+    for (int i = tid; i < SORT_CHUNK; i += 1024) s[i] = (base + i < n) ? make_key(scores[(int64_t)img * nmax + base + i], (u32)(base + i)) : ~0ull;
+    __syncthreads();
+    for (int k = 2; k <= SORT_CHUNK; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+            for (int q = 0; q < SORT_CHUNK / 2 / 1024; ++q) {
+                const int t = tid + 1024 * q;
+                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
+                const u64 a = s[i], b = s[l];
+                const bool asc = (i & k) == 0;                 // k = SORT_CHUNK: ascending throughout
+                if ((a > b) == asc) { s[i] = b; s[l] = a; }
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < SORT_CHUNK; i += 1024) g[i] = s[i];
+}
+
+__global__ __launch_bounds__(256) void k_nms_merge_rank(const float4 *__restrict__ boxes, const u64 *__restrict__ keys,
+                                                        const int32_t *__restrict__ counts, int64_t nmax, int64_t Np, int64_t Np2,
+                                                        float *x1, float *y1, float *x2, float *y2, float *area, int32_t *order)
+{
+    __shared__ u64 s_max[16][64];                                 // last key of every 64-key block of every chunk
+    const int img = blockIdx.y, tid = threadIdx.x;
+    const int n = counts ? counts[img] : (int)nmax;
+    const u64 *kimg = keys + (int64_t)img * Np2;
+    const int nchunks = (int)(Np2 / SORT_CHUNK);                  // 2 .. 16
+    for (int t = tid; t < nchunks * 64; t += 256) s_max[t >> 6][t & 63] = kimg[(int64_t)(t >> 6) * SORT_CHUNK + (t & 63) * 64 + 63];
+    __syncthreads();
+    const int64_t e = (int64_t)blockIdx.x * 256 + tid;
+    const int c = (int)(e / SORT_CHUNK);
+    const u64 K = kimg[e];
+    int rank = (int)(e % SORT_CHUNK);
+    int blk[16];
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) {                             // blocks of chunk cc that lie wholly before K
+        int b = 0;
+        if (cc < nchunks && cc != c) {
+#pragma unroll
+            for (int st = 32; st > 0; st >>= 1) {
+                const u64 v = s_max[cc][b + st - 1];
+                if (cc < c ? v <= K : v < K) b += st;
+            }
+            if (b == 63) { const u64 v = s_max[cc][63]; if (cc < c ? v <= K : v < K) b = 64; }
+        }
+        blk[cc] = b;
+    }
+    int in[16];
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc) in[cc] = 0;
+#pragma unroll
+    for (int st = 32; st > 0; st >>= 1) {                         // and the keys of the next block: the chunks' loads of a step in flight together
+        u64 v[16];
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc)
+            v[cc] = (cc < nchunks && cc != c && blk[cc] < 64) ? kimg[(int64_t)cc * SORT_CHUNK + blk[cc] * 64 + in[cc] + st - 1] : ~0ull;
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc)
+            if (cc < nchunks && cc != c && blk[cc] < 64 && (cc < c ? v[cc] <= K : v[cc] < K)) in[cc] += st;
+    }
+#pragma unroll
+    for (int cc = 0; cc < 16; ++cc)
+        if (cc < nchunks && cc != c) rank += blk[cc] * 64 + in[cc];
+    // (inside a block the search covers offsets 0 .. 62 + one more step: the block's last key is not before K, or blk would be larger)
+    if (rank < Np) gather_sorted(boxes + (int64_t)img * nmax, K, rank < n, (int64_t)img * Np + rank, x1, y1, x2, y2, area, order);
+}
+
 __global__ __launch_bounds__(256) void k_nms_gather(const float4 *__restrict__ boxes, const u64 *__restrict__ keys,
                                                     const int32_t *__restrict__ counts, int64_t nmax, int64_t Np, int64_t Np2,
                                                     float *x1, float *y1, float *x2, float *y2, float *area, int32_t *order)
@@ -1922,6 +2003,12 @@ case 512: launch_sort_small<512>(w, boxes, scores, counts, batch, nmax, st); bre
     case 1024: launch_sort_small<1024>(w, boxes, scores, counts, batch, nmax, st); break;
     case 2048: launch_sort_small<2048>(w, boxes, scores, counts, batch, nmax, st); break;
     case 4096: launch_sort_small<4096>(w, boxes, scores, counts, batch, nmax, st); break;
+    case 8192: case 16384: case 32768: case 65536:
+        hipLaunchKernelGGL(k_nms_sort_chunks, dim3((unsigned)(w.Np2 / SORT_CHUNK), (unsigned)batch), dim3(1024), 0, st, scores, counts, nmax,
+                           w.Np2, w.keys);
+        hipLaunchKernelGGL(k_nms_merge_rank, dim3((unsigned)(w.Np2 / 256), (unsigned)batch), dim3(256), 0, st, (const float4 *)boxes, w.keys,
+                           counts, nmax, w.Np, w.Np2, w.x1, w.y1, w.x2, w.y2, w.area, w.order);
+        break;
     default: {
         const int64_t Np2 = w.Np2;
         hipLaunchKernelGGL(k_nms_make_keys, dim3((unsigned)(Np2 / 256), (unsigned)batch), dim3(256), 0, st, scores, counts, nmax, Np2, w.keys);
