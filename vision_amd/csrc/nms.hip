@@ -224,9 +224,13 @@ __global__ __launch_bounds__(1024) void k_nms_sort_chunks(const float *__restric
     const int64_t base = (int64_t)blockIdx.x * SORT_CHUNK;
     u64 *g = keys + (int64_t)img * Np2 + base;
     for (int i = tid; i < SORT_CHUNK; i += 1024) s[i] = (base + i < n) ? make_key(scores[(int64_t)img * nmax + base + i], (u32)(base + i)) : ~0ull;
-    __syncthreads();
+    // (wave-local steps without workgroup barriers: see k_nms_sort_small)
+    bool crossed = true;
     for (int k = 2; k <= SORT_CHUNK; k <<= 1) {
         for (int j = k >> 1; j > 0; j >>= 1) {
+            const bool cross = j >= 128;
+            if (cross || crossed) __syncthreads();
+            else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 #pragma unroll
             for (int q = 0; q < SORT_CHUNK / 2 / 1024; ++q) {
                 const int t = tid + 1024 * q;
@@ -235,9 +239,10 @@ __global__ __launch_bounds__(1024) void k_nms_sort_chunks(const float *__restric
                 const bool asc = (i & k) == 0;                 // k = SORT_CHUNK: ascending throughout
                 if ((a > b) == asc) { s[i] = b; s[l] = a; }
             }
-            __syncthreads();
+            crossed = cross;
         }
     }
+    __syncthreads();
     for (int i = tid; i < SORT_CHUNK; i += 1024) g[i] = s[i];
 }
 
@@ -1541,7 +1546,8 @@ __global__ __launch_bounds__(256, 4) void k_nms_band(const float4 *__restrict__ 
                                                      const int32_t *__restrict__ start, NmsHdr *__restrict__ hdr,
                                                      const int32_t *__restrict__ counts, int64_t nmax, int64_t Np,
                                                      int64_t lcap, int lsh, float thr, float thr_below, double mid,
-                                                     u64 *__restrict__ maskws, int64_t W, int32_t *__restrict__ lcnt, int force)
+                                                     u64 *__restrict__ maskws, int64_t W, int32_t *__restrict__ lcnt, int force,
+                                                     u32 *__restrict__ mc)
 {
     __shared__ float4 rbox[64];
     __shared__ float rarea[64];
@@ -1551,6 +1557,8 @@ __global__ __launch_bounds__(256, 4) void k_nms_band(const float4 *__restrict__ 
     __shared__ int s_ocnt[4][64], s_obase[4][64];
     const int img = blockIdx.z;
     NmsHdr *h = hdr + img;
+    if (blockIdx.x == 0 && blockIdx.y == 0)                        // what k_nms_resolve_mc's workgroups tell each other starts at zero
+        for (int i = threadIdx.x; i < 4352; i += 256) mc[(int64_t)img * 4352 + i] = 0u;     // MC_WORDS
     if (h->mode != 0) return;
     if (force != 2 && h->estsum > NMS_EST_MAX) {                   // too many pairs to list (k_nms_estimate): the dense path does this image
         if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *(volatile int32_t *)&h->mode = 1;
@@ -2065,10 +2073,10 @@ static int nms_phase_mask(const int32_t *counts, int64_t batch, int64_t nmax, fl
                                    w.Np, threshold);
             if (tie_even)
                 hipLaunchKernelGGL((k_nms_band<true>), g, dim3(256), 0, (hipStream_t)s, w.bbox, w.bar, w.start, w.hdr, counts, nmax, w.Np,
-                                   w.lcap, w.lsh, threshold, below, mid, w.mask, w.W, w.lcnt, force);
+                                   w.lcap, w.lsh, threshold, below, mid, w.mask, w.W, w.lcnt, force, w.mc);
             else
                 hipLaunchKernelGGL((k_nms_band<false>), g, dim3(256), 0, (hipStream_t)s, w.bbox, w.bar, w.start, w.hdr, counts, nmax, w.Np,
-                                   w.lcap, w.lsh, threshold, below, mid, w.mask, w.W, w.lcnt, force);
+                                   w.lcap, w.lsh, threshold, below, mid, w.mask, w.W, w.lcnt, force, w.mc);
         }
         DG_CHECK_LAUNCH("k_nms_band");
     }
@@ -2089,8 +2097,8 @@ extern "C" int dg_nms_phase_mask(const int32_t *counts, int64_t batch, int64_t n
     return nms_phase_mask(counts, batch, nmax, threshold, ws, ws_bytes, s, true);
 }
 
-extern "C" int dg_nms_phase_reduce(const int32_t *counts, int64_t batch, int64_t nmax, int quirk_drop_last,
-                                   int64_t *keep, int32_t *keep_count, void *ws, size_t ws_bytes, dg_stream_t s)
+static int nms_phase_reduce(const int32_t *counts, int64_t batch, int64_t nmax, int quirk_drop_last,
+                            int64_t *keep, int32_t *keep_count, void *ws, size_t ws_bytes, dg_stream_t s, bool standalone)
 {
     NmsWs w;
     int rc = nms_check("nms_reduce", batch, nmax, ws, ws_bytes, &w);
@@ -2104,7 +2112,8 @@ extern "C" int dg_nms_phase_reduce(const int32_t *counts, int64_t batch, int64_t
     const NmsHdr *hdr = nullptr;
     if (w.pruned && nms_prune_mode() != 0) {
         hdr = w.hdr;
-        if (hipMemsetAsync(w.mc, 0, (size_t)batch * MC_WORDS * 4, st) != hipSuccess) { dg_set_error("nms_reduce: memset failed"); return DG_EHIP; }
+        // (the mask phase's k_nms_band zeroed w.mc; the reduce phase run again on its own -- bench.py times it so -- does it itself)
+        if (standalone && hipMemsetAsync(w.mc, 0, (size_t)batch * MC_WORDS * 4, st) != hipSuccess) { dg_set_error("nms_reduce: memset failed"); return DG_EHIP; }
         hipLaunchKernelGGL(k_nms_resolve_mc, dim3(MC_G, (unsigned)batch), dim3(1024), 0, st, w.hdr, counts, nmax, w.Np, w.W, w.lcap, w.lsh,
                            w.ecap, w.lcnt, w.order, w.mask, w.mc, nms_fp_rounds(), quirk_drop_last, keep, keep_count);
         hipLaunchKernelGGL(k_nms_reduce_csr<true>, dim3((unsigned)batch), dim3(1024), 0, st, w.mask, w.order, counts, nmax, w.Np,
@@ -2164,6 +2173,12 @@ extern "C" int dg_nms_phase_reduce(const int32_t *counts, int64_t batch, int64_t
     return DG_OK;
 }
 
+extern "C" int dg_nms_phase_reduce(const int32_t *counts, int64_t batch, int64_t nmax, int quirk_drop_last,
+                                   int64_t *keep, int32_t *keep_count, void *ws, size_t ws_bytes, dg_stream_t s)
+{
+    return nms_phase_reduce(counts, batch, nmax, quirk_drop_last, keep, keep_count, ws, ws_bytes, s, true);
+}
+
 extern "C" int dg_nms_batched_f32(const float *boxes, const float *scores, const int32_t *counts, int64_t batch, int64_t nmax,
                                   float threshold, int quirk_drop_last, int64_t *keep, int32_t *keep_count,
                                   void *ws, size_t ws_bytes, dg_stream_t s)
@@ -2172,7 +2187,7 @@ extern "C" int dg_nms_batched_f32(const float *boxes, const float *scores, const
     if (rc) return rc;
     rc = nms_phase_mask(counts, batch, nmax, threshold, ws, ws_bytes, s, false);
     if (rc) return rc;
-    return dg_nms_phase_reduce(counts, batch, nmax, quirk_drop_last, keep, keep_count, ws, ws_bytes, s);
+    return nms_phase_reduce(counts, batch, nmax, quirk_drop_last, keep, keep_count, ws, ws_bytes, s, false);
 }
 
 // diagnostic: which path image `img` of the last call on this workspace took (synchronous; tests and bench.py use it to
