@@ -12,7 +12,8 @@ int main(int argc, char **argv)
     std::vector<double> rois(4 * (size_t)n);
     std::vector<int64_t> idx(n);
     for (int i = 0; i < n; ++i) {
-        double x = u(rng) * 0.7, y = u(rng) * 0.7, w = 0.02 + 0.28 * u(rng), h = 0.02 + 0.28 * u(rng);
+        const double lo = argc > 3 ? atof(argv[2]) : 0.02, hi = argc > 3 ? atof(argv[3]) : 0.30;      // RoI side as a fraction of the map
+        double w = lo + (hi - lo) * u(rng), h = lo + (hi - lo) * u(rng), x = u(rng) * (argc > 3 ? 1.0 - w : 0.7), y = u(rng) * (argc > 3 ? 1.0 - h : 0.7);
         rois[4 * i] = x; rois[4 * i + 1] = y; rois[4 * i + 2] = x + w; rois[4 * i + 3] = y + h;
         idx[i] = i / 2000;
     }

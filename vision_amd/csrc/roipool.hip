@@ -467,75 +467,85 @@ __device__ __forceinline__ void direct_max_bin(const float *__restrict__ base, i
 // Wide crops (more than 24 cells wide, or strips taller than the LDS ring holds): one-pass exact argmax straight from the
 // map with NO per-cell address arithmetic.  All bin geometry is wave-uniform, so per task each lane keeps 7 x XW byte
 // offsets (column of position j of bin i, clamped to the bin, + this lane's channel) and every load is
-// `global_load_dword v, voff[i][j], s[row base]`; a row of the strip is 7 x XW coalesced 256-byte loads held in
-// registers, the next row's loads are in flight while the current row is compared.  Per cell: one compare, one select of
-// the position code (r*8 + j, kept in XW registers that advance by 8 per row), one select of the value (its own bits:
-// -0 stays -0).  A clamped re-read repeats the bin's last cell and cannot win the strict compare; with NANSAFE a NaN
-// always wins (ATen) and the decode clamps.  Results go straight into the [channel][bin] LDS image.
+// `global_load_dword v, voff[i][j], s[row base]`; a row of the crop is 7 x XW coalesced 256-byte loads held in
+// registers.  Per cell: one compare, one select of the position code (r*8 + j, kept in XW registers that advance by 8 per
+// row), one select of the value (its own bits: -0 stays -0).  A clamped re-read repeats the bin's last cell and cannot win
+// the strict compare; with NANSAFE a NaN always wins (ATen) and the decode clamps.  Results go straight into the
+// [channel][bin] LDS image.
+// Round 3: the rows of the whole crop are ONE stream through NB register buffers -- NB - 1 rows are in flight while one is
+// compared, and the stream does not stop at strip boundaries (a row that two strips share is compared twice from the same
+// registers).  Round 2's version kept one row in flight and restarted at each of the seven strips: a task of 26 row steps
+// waited out an L2 round trip at nearly every one of them (8 waves per CU cannot hide it), which is what held the
+// U(0.1,0.9) proposal mix at 0.24 of the store-bound rate.
 // (The direct path this replaces spent ~10 VALU instructions per cell on 64-bit address and index arithmetic.)
-template <int XW, bool NANSAFE>
+template <int XW, bool NANSAFE, int NB>
 __device__ __forceinline__ void roi_task_wide(const char *__restrict__ imgc0, int pixbytes, int W, int lane, int x1, int y1, int x2,
                                               int y2, float *__restrict__ sval, unsigned short *__restrict__ sidx)
 {
     const int Lh = y2 - y1, Lw = x2 - x1;
     int ws[RP], we[RP];
-    unsigned voff[RP][XW];
+    // XW >= 5 is the widest bin itself and every bin is at most two cells narrower: positions 0 .. XW-3 exist in all seven
+    // bins, so their offsets (j pixels + this lane's channel) are shared and the bin's first column goes into the scalar
+    // base; only the last two positions are clamped per bin.  XW + 12 offset registers instead of 7 XW -- what pays for the
+    // third row buffer.  (XW == 4 also serves narrower bins and keeps the full table.)
+    constexpr bool SHARED = XW >= 5;
+    constexpr int NT = SHARED ? 1 : RP;
+    unsigned voff[NT][XW], voffA[RP], voffB[RP];
 #pragma unroll
     for (int i = 0; i < RP; ++i) {
         ws[i] = (i * Lw) / RP;                          // relative to x1 (uniform)
         we[i] = ((i + 1) * Lw + RP - 1) / RP;
+        const int w = we[i] - ws[i];
+        voffA[i] = (unsigned)(min(XW - 2, w - 1) * pixbytes + lane * 4);
+        voffB[i] = (unsigned)(min(XW - 1, w - 1) * pixbytes + lane * 4);
 #pragma unroll
-        for (int j = 0; j < XW; ++j) voff[i][j] = (unsigned)(min(ws[i] + j, we[i] - 1) * pixbytes + lane * 4);
+        for (int j = 0; j < XW; ++j)
+            if (i < NT) voff[i < NT ? i : 0][j] = (unsigned)((SHARED ? j : min(ws[i] + j, we[i] - 1)) * pixbytes + lane * 4);
     }
     auto load_row = [&](int y, float (&v)[RP][XW]) {
         const char *rowg = imgc0 + (int64_t)(y * W + x1) * pixbytes;                   // uniform
 #pragma unroll
-        for (int i = 0; i < RP; ++i)
+        for (int i = 0; i < RP; ++i) {
+            const char *bing = SHARED ? rowg + ws[i] * pixbytes : rowg;                // uniform
 #pragma unroll
-            for (int j = 0; j < XW; ++j) v[i][j] = *reinterpret_cast<const float *>(rowg + voff[i][j]);
+            for (int j = 0; j < XW; ++j) {
+                const unsigned o = !SHARED ? voff[i < NT ? i : 0][j] : (j == XW - 2 ? voffA[i] : (j == XW - 1 ? voffB[i] : voff[0][j]));
+                v[i][j] = *reinterpret_cast<const float *>(bing + o);
+            }
+        }
     };
-#pragma unroll 1
-    for (int ph = 0; ph < RP; ++ph) {
-        const int hs = y1 + (ph * Lh) / RP, he = y1 + ((ph + 1) * Lh + RP - 1) / RP;
-        float best[RP];
-        int code[RP], vcode[XW];
+    // the strip being filled: rows hs .. he - 1 of the map (uniform)
+    int ph = 0, hs = y1, he = y1 + (Lh + RP - 1) / RP;
+    float best[RP];
+    int code[RP], vcode[XW];
+    auto reset = [&]() {
 #pragma unroll
         for (int i = 0; i < RP; ++i) { best[i] = -INFINITY; code[i] = 0; }
 #pragma unroll
         for (int j = 0; j < XW; ++j) vcode[j] = j;
-        auto scan_row = [&](const float (&v)[RP][XW]) {
+    };
+    auto scan_row = [&](const float (&v)[RP][XW]) {
 #pragma unroll
-            for (int j = 0; j < XW; ++j) {
+        for (int j = 0; j < XW; ++j) {
 #pragma unroll
-                for (int i = 0; i < RP; ++i) {
-                    const float a = v[i][j];
-                    if (NANSAFE) {
-                        const bool g = (a > best[i]) || (a != a);
-                        code[i] = g ? vcode[j] : code[i];
-                        best[i] = g ? a : best[i];
-                    } else {
-                        // value by v_max (full rate; v_cmp / v_cndmask are half rate): equal to the selected value except
-                        // that max(-0, +0) = +0 while the strict compare keeps the earlier -0 -- repaired after the strip
-                        code[i] = (a > best[i]) ? vcode[j] : code[i];
-                        best[i] = vmaxf(best[i], a);
-                    }
+            for (int i = 0; i < RP; ++i) {
+                const float a = v[i][j];
+                if (NANSAFE) {
+                    const bool g = (a > best[i]) || (a != a);
+                    code[i] = g ? vcode[j] : code[i];
+                    best[i] = g ? a : best[i];
+                } else {
+                    // value by v_max (full rate; v_cmp / v_cndmask are half rate): equal to the selected value except
+                    // that max(-0, +0) = +0 while the strict compare keeps the earlier -0 -- repaired when the strip ends
+                    code[i] = (a > best[i]) ? vcode[j] : code[i];
+                    best[i] = vmaxf(best[i], a);
                 }
             }
-#pragma unroll
-            for (int j = 0; j < XW; ++j) vcode[j] += 8;
-        };
-        // two row buffers, used alternately (the loop is unrolled by two so that neither is ever copied)
-        float ra[RP][XW], rb[RP][XW];
-        load_row(hs, ra);
-#pragma unroll 1
-        for (int y = hs; y < he; y += 2) {
-            load_row(min(y + 1, he - 1), rb);               // past the strip: a re-read whose result is not used
-            scan_row(ra);
-            if (y + 1 < he) {                               // uniform
-                load_row(min(y + 2, he - 1), ra);
-                scan_row(rb);
-            }
         }
+#pragma unroll
+        for (int j = 0; j < XW; ++j) vcode[j] += 8;
+    };
+    auto finish_strip = [&]() {
         const int ibase = hs * W + x1;
         int pos[RP];
 #pragma unroll
@@ -556,6 +566,32 @@ __device__ __forceinline__ void roi_task_wide(const char *__restrict__ imgc0, in
         for (int i = 0; i < RP; ++i) {
             sval[lane * RBINS + ph * RP + i] = best[i];
             sidx[lane * RBINS + ph * RP + i] = (unsigned short)pos[i];
+        }
+    };
+    reset();
+    float buf[NB][RP][XW];                                // used in rotation; the row loop is unrolled by NB so that none is ever copied
+#pragma unroll
+    for (int b = 0; b + 1 < NB; ++b) load_row(min(y1 + b, y2 - 1), buf[b]);
+#pragma unroll 1
+    for (int y = y1; y < y2; y += NB) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int yy = y + b;
+            if (yy < y2) {                                  // uniform
+                load_row(min(yy + NB - 1, y2 - 1), buf[(b + NB - 1) % NB]);   // past the crop: a re-read whose result is not used
+                scan_row(buf[b]);
+                // strips that end with this row (short crops: several may); the next strip starts on this row or the next
+                // (floor((ph+1) Lh / 7) >= ceil((ph+1) Lh / 7) - 1), never earlier
+                while (ph < RP && yy == he - 1) {
+                    finish_strip();
+                    ++ph;
+                    if (ph == RP) break;
+                    hs = y1 + (ph * Lh) / RP; he = y1 + ((ph + 1) * Lh + RP - 1) / RP;
+                    reset();
+                    if (hs > yy) break;
+                    scan_row(buf[b]);
+                }
+            }
         }
     }
 }
@@ -782,14 +818,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
             const int maxw = qw + (rw > 1 ? 2 : rw);
             {
                 const char *imgc0 = reinterpret_cast<const char *>(nhwc + ((int64_t)b * H * W) * C + c0);
-#define WIDE(XWV) do { if (may_nan) roi_task_wide<XWV, true>(imgc0, C * 4, W, lane, x1, y1, x2, y2, sval, sidx); \
-                       else roi_task_wide<XWV, false>(imgc0, C * 4, W, lane, x1, y1, x2, y2, sval, sidx); } while (0)
-                switch (maxw) {
-                case 1: case 2: case 3: case 4: WIDE(4); break;
-                case 5: WIDE(5); break;
-                case 6: WIDE(6); break;
-                case 7: WIDE(7); break;
-                default: WIDE(8); break;
+#define WIDE(XWV, NBV) do { if (may_nan) roi_task_wide<XWV, true, NBV>(imgc0, C * 4, W, lane, x1, y1, x2, y2, sval, sidx); \
+                            else roi_task_wide<XWV, false, NBV>(imgc0, C * 4, W, lane, x1, y1, x2, y2, sval, sidx); } while (0)
+                switch (maxw) {                               // row buffers: as many as the registers hold
+                case 1: case 2: case 3: case 4: WIDE(4, 3); break;
+                case 5: WIDE(5, 3); break;
+                case 6: WIDE(6, 3); break;
+                case 7: WIDE(7, 3); break;
+                default: WIDE(8, 2); break;
                 }
 #undef WIDE
                 emit();
@@ -929,6 +965,14 @@ __global__ __launch_bounds__(256) void k_roi_fill(const int32_t *__restrict__ wi
     int r;
     const int start = wave_group_add(cursor, valid ? win[5 * i + 4] : 0, valid, &r);
     if (valid) list[start + r] = (int32_t)i;
+}
+
+// one image: its list is every RoI in order (no count / scan / fill: three launches that cost a single-image backward 15 % of its time)
+__global__ __launch_bounds__(256) void k_roi_list_single(int64_t n, int32_t *__restrict__ off, int32_t *__restrict__ list)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) list[i] = (int32_t)i;
+    if (i == 0) { off[0] = 0; off[1] = (int32_t)n; }
 }
 
 // LDS float accumulate.  Measured on MI355X (tools/ubench/lds_atomic.hip): a wave-wide LDS f32 atomic add costs
@@ -1360,10 +1404,14 @@ static int roipool_bwd(const float *grad_out, const void *argmax, bool a16, cons
         if (n == 0) return hipMemsetAsync(grad_in, 0, (size_t)B * C * HW * 4, st) == hipSuccess ? DG_OK : DG_EHIP;
         return dg_roipool_bwd_generic(grad_out, argmax, a16, win, n, B, C, H, W, PH, PW, mode, grad_in, st);
     }
-    if (hipMemsetAsync(w.cnt, 0, (size_t)B * 4, st) != hipSuccess) { dg_set_error("roipool_bwd: memset failed"); return DG_EHIP; }
-    if (n > 0) hipLaunchKernelGGL(k_roi_count, dim3((unsigned)dg_cdiv(n, 256)), dim3(256), 0, st, win, n, w.cnt);
-    hipLaunchKernelGGL(k_roi_scan, dim3(1), dim3(1024), 0, st, w.cnt, (int)B, w.off, w.cursor);
-    if (n > 0) hipLaunchKernelGGL(k_roi_fill, dim3((unsigned)dg_cdiv(n, 256)), dim3(256), 0, st, win, n, w.cursor, w.list);
+    if (B == 1) {
+        hipLaunchKernelGGL(k_roi_list_single, dim3((unsigned)dg_cdiv(n > 0 ? n : 1, 256)), dim3(256), 0, st, n, w.off, w.list);
+    } else {
+        if (hipMemsetAsync(w.cnt, 0, (size_t)B * 4, st) != hipSuccess) { dg_set_error("roipool_bwd: memset failed"); return DG_EHIP; }
+        if (n > 0) hipLaunchKernelGGL(k_roi_count, dim3((unsigned)dg_cdiv(n, 256)), dim3(256), 0, st, win, n, w.cnt);
+        hipLaunchKernelGGL(k_roi_scan, dim3(1), dim3(1024), 0, st, w.cnt, (int)B, w.off, w.cursor);
+        if (n > 0) hipLaunchKernelGGL(k_roi_fill, dim3((unsigned)dg_cdiv(n, 256)), dim3(256), 0, st, win, n, w.cursor, w.list);
+    }
     // channels per workgroup: as many as fit ~32 KiB of LDS, but keep >= ~1024 workgroups when possible
     int CB = 1;
     while (CB < 4 && (int64_t)CB * 2 * HW * 4 <= 32 * 1024 && CB * 2 <= C) CB *= 2;      // 4 channels: 16-byte vector path
@@ -1376,6 +1424,8 @@ static int roipool_bwd(const float *grad_out, const void *argmax, bool a16, cons
     int NT = 256;
     if (mode == DG_POOL_MAX && C % 16 == 0 && (int64_t)16 * HW * 4 <= 144 * 1024 && B * (C / 16) >= 256) { CB = 16; NT = 1024; }
     else if (mode == DG_POOL_MAX && C % 8 == 0 && (int64_t)8 * HW * 4 <= 72 * 1024 && B * (C / 8) >= 512) { CB = 8; NT = 512; }
+    // (one image of 2000 RoIs, round 3: the wider slices do not help below those image counts -- 4 channels x 8 list splits
+    //  103.5 us, 8 x 8 103.3, 16 x 8 105.7, and every other split count 121-136 us)
     int64_t S = 1;                                     // RoI-list splits when there are too few (image, slice) pairs
     while (S < 16 && B * dg_cdiv(C, CB) * S < 1024 && n / (B * S * 2) >= 64) S *= 2;
     dim3 grid((unsigned)dg_cdiv(C, CB), (unsigned)B, (unsigned)S);
