@@ -478,6 +478,11 @@ __device__ __forceinline__ void direct_max_bin(const float *__restrict__ base, i
 // waited out an L2 round trip at nearly every one of them (8 waves per CU cannot hide it), which is what held the
 // U(0.1,0.9) proposal mix at 0.24 of the store-bound rate.
 // (The direct path this replaces spent ~10 VALU instructions per cell on 64-bit address and index arithmetic.)
+// What bounds it now is the compare + select per cell (v_cmp / v_cndmask are half rate: 20 cycles per cell and wave with the
+// v_max; in-kernel stamps put 60 % of the U(0.1,0.9) mix's time in this scan, 7 % in the output phase).  Measured and not kept:
+// cells only maxed (v_max3), the winning ROW recorded per bin and row, the column found after the last strip by loading
+// the winning row's cells again -- each lane has its own row then, so those loads touch 64 lines instead of 2 and the
+// mix ran 9.5 ms instead of 6.1.
 template <int XW, bool NANSAFE, int NB>
 __device__ __forceinline__ void roi_task_wide(const char *__restrict__ imgc0, int pixbytes, int W, int lane, int x1, int y1, int x2,
                                               int y2, float *__restrict__ sval, unsigned short *__restrict__ sidx)
