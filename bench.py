@@ -362,21 +362,23 @@ def extra_stress(d, n=65536):
             t_red = ev_median(lambda: lib.dg_nms_phase_reduce(None, 1, n, 1, _abi.ptr(keep), _abi.ptr(kc), _abi.ptr(ws), nb, sp), 50, 20)
             tot = t_sort + t_mask + t_red
             t_all = ev_median(lambda: ops.nms_batched(bt, st, None, thr, True, keep=keep, keep_count=kc), 50, 20)
-            mode, fpdone, rounds, npairs = ops.nms_path_info(d.dev, 1, n)[:4]
+            mode, fpdone, rounds, npairs, cpb, est = ops.nms_path_info(d.dev, 1, n)
             kept = int(kc.item())
             a_n = 20.0 * n + n * n / 4.0 + 8.0 * kept            # A(N) = 20 N + N^2/8 written + N^2/8 read + 8 K
             r[tag] = {"sort_ms": t_sort, "mask_ms": t_mask, "reduce_ms": t_red, "whole_call_ms": t_all, "kept": kept,
                       "boxes_per_s": n / t_all * 1e3,
-                      "path": ("pruned: x-bucket band pair search + fixed-point keep list" if mode == 0 else "dense mask"),
+                      "path": ("pruned: x-bucket band pair search + fixed-point keep list on 64 workgroups" if mode == 0 else "dense mask"),
                       "fixed_point_rounds": rounds if mode == 0 and fpdone else None, "suppressing_pairs": npairs if mode == 0 else None,
+                      "candidates_per_box": cpb, "estimated_pairs_per_box": est,
                       "survey_A_N_frac": a_n / (t_all * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                       "mask_hbm_frac": ((n * n / 16.0 + 20 * n) / (t_mask * 1e-3) / 1e9 / HBM_PEAK_GBPS) if mode == 1 else None,
                       "mask_valu_frac": valu_frac("k_nms_mask", n, t_mask) if mode == 1 else None}
     r["note"] = ("config 5 (replicas only).  survey_A_N_frac = SURVEY 8(d)'s A(N) (which prices an N x N mask written and read) over "
                  "the whole call's time and 8 TB/s: the pruned path never forms that mask -- pairs of boxes that do not overlap cannot "
                  "suppress, so it searches a band of the x-bucket order and moves a few MB -- which is why this is an equivalent rate, "
-                 "not memory traffic; dense sets take the dense mask (k_nms_mask, VALU-bound: mask_valu_frac = SQ_INSTS_VALU x 64 / time "
-                 "over the chip's 7.86e13 lane-ops/s); phases are timed one by one (sort includes the x-bucket sort of the pruned "
+                 "not memory traffic; the path is chosen per image from the candidate pairs per box (x-bucket order) and, once the "
+                 "threshold is known, from the suppressing pairs of 1024 sampled boxes (more than 128 per box: dense mask, k_nms_mask, "
+                 "VALU-bound: mask_valu_frac = SQ_INSTS_VALU x 64 / time over the chip's 7.86e13 lane-ops/s); phases are timed one by one (sort includes the x-bucket sort of the pruned "
                  "path), whole_call_ms is dg_nms_batched_f32 as one call; medians of 50 launches after 20 warm-up")
     return r
 
@@ -418,7 +420,7 @@ def extra_kmeans(d, n_total=10_000_000, iters=30):
          "sharded_loop": km.graph_state if d.world > 1 else "single device: dg_kmeans_iou_run",
          "comm": km.comm_state if d.world > 1 else None,
          "device_ms_per_iter_this_shard": ms, "iter_hbm_frac": (12.0 * per) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-         "iter_valu_frac": valu_frac("k_kmeans_step", per, ms),
+         "iter_valu_frac": valu_frac("k_kmeans_step", per, ms) if d.world > 1 else None,   # (one device: the prepared path, see box_loop)
          "centers": km.cluster_centers_.round(6).tolist(), "loops": loops,
          "best_iters_per_s": max([iters / sec] + [v["iters_per_s"] for v in (loops or {}).values() if "iters_per_s" in v]),
          "note": "config 4, strong scaling: 10M boxes sharded; per iteration ONE launch (the centroid update is the prologue of "

@@ -1,7 +1,8 @@
-"""Fold the per-pass CSVs of tools/profile_pmc.sh (gpurun_out/r02_pmc/<workload>_<pass>.csv) into
-   profiles/r02_pmc_<workload>.csv  : one row per (kernel, grid, counter) for OUR kernels (k_*), as measured
-   profiles/r02_pmc_summary.csv     : one row per (workload, kernel, grid): duration, HBM bytes, instruction counts, fractions
-   profiles/traffic.json            : per-launch HBM bytes and VALU wave-instructions bench.py reads (roofline.traffic, valu_frac)
+"""Fold the per-pass CSVs of tools/profile_pmc.sh (gpurun_out/<tag>_pmc/<workload>_<pass>.csv; tag = argv[1], default r03) into
+   profiles/<tag>_pmc_<workload>.csv  : one row per (kernel, grid, counter) for OUR kernels (k_*), as measured
+   profiles/<tag>_pmc_summary.csv     : one row per (workload, kernel, grid): duration, HBM bytes, instruction counts, fractions
+   profiles/traffic.json              : per-launch HBM bytes and VALU wave-instructions bench.py reads (roofline.traffic, valu_frac),
+                                        written FROM SCRATCH from this tag's passes (earlier rounds' figures stay in their own CSVs)
 HBM bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE / WRITE_SIZE are in KB and, on gfx950, FETCH_SIZE tallies 16-byte-per-lane
 streaming reads at half their size (MI355X_MICROARCH.md, HBM section)."""
 import collections
@@ -12,9 +13,9 @@ import os
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-SRC = os.path.join(ROOT, "gpurun_out", "r02_pmc")
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+SRC = os.path.join(ROOT, "gpurun_out", f"{TAG}_pmc")
 OUT = os.path.join(ROOT, "profiles")
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r02"
 VALU_PEAK = 256 * 4 * 32 * 2.4e9
 
 # algorithmic bytes per launch of the profiled workloads (SURVEY 8(d) per-unit figures x units; tools/prof_roi.py sizes)
@@ -23,13 +24,14 @@ ALGO = {
     ("bwd", "k_roipool_bwd"): 512000 * 200704 + 256 * 3891200,
     ("fwdwide", "k_roipool_fwd"): 64000 * 200704 + 32 * 3891200 + 64000 * 20,
     ("kmeans", "k_kmeans_step"): 12 * 10_000_000,
+    ("kmeans_prepared", "k_kc_iter"): 12 * 10_000_000,        # SURVEY's bytes as an equivalent rate: the kernel reads pieces, not boxes
     ("kmeans_shard", "k_kmeans_step"): 12 * 1_250_000,
     ("nms64k", "k_nms_mask"): 65536 * 65536 // 16 + 20 * 65536,
     ("nms256", "k_nms_mask"): 256 * (2048 * 2048 // 16 + 20 * 2048),
     ("pairwise", "k_iou_pairwise_f32"): 4 * 65536 * 65536 + 32 * 65536,
 }
-UNITS = {"fwd": 512000, "bwd": 512000, "fwdwide": 64000, "kmeans": 10_000_000, "kmeans_shard": 1_250_000, "nms64k": 65536,
-         "nms256": 512000, "pairwise": 65536}
+UNITS = {"fwd": 512000, "bwd": 512000, "fwdwide": 64000, "kmeans": 10_000_000, "kmeans_prepared": 10_000_000, "kmeans_shard": 1_250_000,
+         "nms64k": 65536, "nms64k_dense": 65536, "nms256": 512000, "nms2000": 2000, "pairwise": 65536}
 
 rows = collections.defaultdict(dict)          # (workload, kernel, grid) -> {counter: value, "us": duration}
 per_workload = collections.defaultdict(list)
@@ -55,7 +57,10 @@ cols = ["FETCH_SIZE", "WRITE_SIZE", "SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_LDS",
         "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_ANY", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_WAIT_ANY",
         "SQ_WAIT_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "GRBM_GUI_ACTIVE"]
 traffic_path = os.path.join(OUT, "traffic.json")
-traffic = json.load(open(traffic_path)) if os.path.exists(traffic_path) else {}
+traffic = {"_how": f"tools/profile_pmc.sh + tools/pmc_collect.py {TAG}: rocprofv3 --pmc, one pass per run (FETCH_SIZE; WRITE_SIZE; two SQ passes; GRBM), "
+                   f"python3 tools/prof_roi.py <workload>; values per launch; HBM bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024, FETCH_SIZE doubled as "
+                   f"MI355X_MICROARCH.md prescribes for gfx950 (16-byte-per-lane streaming reads are tallied at half their size); "
+                   f"sources: profiles/{TAG}_pmc_*.csv"}
 traffic.setdefault("valu_insts_per_launch", {})
 traffic.setdefault(f"{TAG}_hbm_bytes_per_launch", {})
 seen_valu, seen_hbm = {}, {}

@@ -1,5 +1,5 @@
 """Profiling driver: runs one hot-path phase a few times (used under rocprofv3).
-usage: python3 tools/prof_roi.py {fwd|bwd|fwdwide|kmeans|kmeans_shard|nms64k|nms256|pairwise} [images] [a32]   (RoI pooling: uint16 argmax unless a32)"""
+usage: python3 tools/prof_roi.py {fwd|bwd|fwdwide|kmeans|kmeans_prepared|kmeans_shard|nms64k|nms64k_dense|nms256|nms2000|pairwise} [images] [a32]   (RoI pooling: uint16 argmax unless a32)"""
 import os
 import sys
 
@@ -35,9 +35,15 @@ elif what in ("kmeans", "kmeans_shard"):
     acc = torch.zeros(17, dtype=torch.int64, device=dev)
     for _ in range(4):
         ops.kmeans_step(wh, cent, labels, acc)
-elif what == "nms64k":
-    b, s = wl.stress_boxes(0, 65536, dense=False)
-    for _ in range(2):
+elif what == "kmeans_prepared":
+    from vision_amd import cluster
+    wh = torch.from_numpy(wl.anchor_wh(0, 10_000_000)).to(dev)
+    km = cluster.kmean(5, 42)
+    km.fit(wh, init_centers=cluster.kmean.init_centers(wl.anchor_wh(0, 10_000_000), 5, 42), fixed_iters=30)
+    km._run_iters(0, 30)
+elif what in ("nms64k", "nms64k_dense"):
+    b, s = wl.stress_boxes(0, 65536, dense=what == "nms64k_dense")
+    for _ in range(3):
         ops.nms_batched(torch.from_numpy(b).to(dev).reshape(1, -1, 4), torch.from_numpy(s).to(dev).reshape(1, -1), None, 0.5, True)
 elif what == "nms256":
     props = [wl.frcnn_proposals(i, 2000) for i in range(256)]
@@ -45,6 +51,11 @@ elif what == "nms256":
     ss = torch.from_numpy(np.stack([s for _, s in props])).to(dev)
     for _ in range(3):
         ops.nms_batched(bb, ss, None, 0.7, True)
+elif what == "nms2000":
+    b, s = wl.frcnn_proposals(0, 2000)
+    bt, st = torch.from_numpy(b).to(dev).reshape(1, -1, 4), torch.from_numpy(s).to(dev).reshape(1, -1)
+    for _ in range(5):
+        ops.nms_batched(bt, st, None, 0.7, True)
 elif what == "pairwise":
     b, s = wl.stress_boxes(0, 65536, dense=False)
     bt = torch.from_numpy(b).to(dev)

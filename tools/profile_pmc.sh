@@ -1,13 +1,13 @@
 #!/bin/bash
 # PMC passes (rocprofv3 --pmc, one pass per run, counters only) for the headline kernels; run on the GPU box:
-#   bash tools/profile_pmc.sh [workload ...]        -> gpurun_out/r02_pmc/<workload>_<pass>.csv
+#   [PMC_TAG=r03] bash tools/profile_pmc.sh [workload ...]        -> gpurun_out/<tag>_pmc/<workload>_<pass>.csv
 # Every pass is its own process under a hard time limit; the first failure ends the script.
 set -e -o pipefail
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
-OUT=gpurun_out/r02_pmc
+OUT=gpurun_out/${PMC_TAG:-r03}_pmc
 mkdir -p $OUT
-WORK=${@:-"fwd:256:a32 bwd:256:a32 fwdwide:32:a32 kmeans kmeans_shard nms64k nms256 pairwise"}
+WORK=${@:-"fwd:256:a32 bwd:256:a32 fwdwide:32:a32 kmeans kmeans_prepared kmeans_shard nms64k nms64k_dense nms256 nms2000 pairwise"}
 declare -A PASS
 PASS[fetch]="FETCH_SIZE"
 PASS[write]="WRITE_SIZE"
