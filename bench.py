@@ -447,9 +447,25 @@ def extra_kmeans(d, n_total=10_000_000, iters=30):
                              "iter_hbm_frac_own_10B": (10.0 * per) / (msb * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                              "iter_valu_frac": valu_frac("k_kmeans_step", per, msb),
                              "same_centers": bool(np.array_equal(kb.cluster_centers_, km.cluster_centers_))}
+            # a whole fit from Python, wall clock (workspace allocation, the one-time grouping by cell, 30 iterations, labels
+            # widened, history read back), second fit of each kind in this process; device time of the grouping alone beside it
+            walls = {}
+            for cells in ("1", "0"):
+                os.environ["DG_KMEANS_CELLS"] = cells
+                best = None
+                for _ in range(3):
+                    torch.cuda.synchronize(); t0 = time.perf_counter()
+                    kp = cluster.kmean(5, 42); kp.fit(shard, init_centers=init, fixed_iters=iters); torch.cuda.synchronize()
+                    dt = (time.perf_counter() - t0) * 1e3
+                    best = dt if best is None else min(best, dt)
+                walls[cells] = best
+            r["fit_30_iters_wall_ms_incl_prepare"] = walls["1"]
+            r["fit_30_iters_wall_ms_box_loop"] = walls["0"]
             os.environ["DG_KMEANS_CELLS"] = "1"
-            t0 = time.perf_counter(); kp = cluster.kmean(5, 42); kp.fit(shard, init_centers=init, fixed_iters=iters); torch.cuda.synchronize()
-            r["fit_30_iters_wall_ms_incl_prepare"] = (time.perf_counter() - t0) * 1e3
+            kp = cluster.kmean(5, 42); kp.fit(shard, init_centers=init, fixed_iters=iters)
+            be = kp._backend
+            if getattr(be, "cells", None) is not None and hasattr(be, "reprepare"):
+                r["prepare_device_ms"] = min(ev_time(be.reprepare, 3, 1) for _ in range(3))
         except Exception as e:  # noqa: BLE001
             r["box_loop"] = {"error": f"{type(e).__name__}: {e}"}
         finally:

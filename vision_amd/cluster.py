@@ -96,9 +96,14 @@ class _HipBackend:
         if cells is not False and mode != "0" and n >= 1 and (mode == "1" or cells is True or n >= _CELLS_MIN_BOXES):
             nb = lib.dg_kmeans_prepared_workspace_bytes(n, k)
             self.cells = (torch.empty(nb, dtype=torch.uint8, device=dev), nb)
-            with torch.cuda.device(dev):
-                _abi.check(lib.dg_kmeans_prepare(_abi.ptr(self.wh), n, k, _abi.ptr(self.labels), _abi.ptr(self.cells[0]), nb,
-                                                 _abi.stream_ptr(dev)))
+            self.reprepare()
+
+    def reprepare(self):
+        """group the boxes (and the current labels) by (w, h) cell again: dg_kmeans_prepare on this fit's workspace"""
+        dev = self.wh.device
+        with torch.cuda.device(dev):
+            _abi.check(_abi.load().dg_kmeans_prepare(_abi.ptr(self.wh), self.wh.shape[0], self.cent.shape[0], _abi.ptr(self.labels),
+                                                     _abi.ptr(self.cells[0]), self.cells[1], _abi.stream_ptr(dev)))
 
     def run_local(self, slot0, iters):
         """single device: `iters` launches issued by one C call (dg_kmeans_iou_run)"""
