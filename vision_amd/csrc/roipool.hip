@@ -1040,12 +1040,19 @@ __device__ __forceinline__ void lds_fadd_px4(float *p, const float (&g)[4])
 // grid: x = channel block (CB channels), y = image.  Dynamic LDS: CB*H*W floats.
 // VEC: CB*49 % 4 == 0 and 16-byte aligned tensors -> each thread moves 4 consecutive elements of one RoI
 // (16-byte loads of grad_out and argmax), two such groups in flight per thread.
-template <int MODE, bool VEC, int NT, bool A16>
+// IDENT (one image): the image's list is every RoI in order -- `list` and `off` are not read, the list has `nident` entries
+// (no list-building launch in front of the kernel).
+template <int MODE, bool VEC, int NT, bool A16, bool IDENT = false>
 __global__ __launch_bounds__(NT) void k_roipool_bwd(const float *__restrict__ grad_out, const void *__restrict__ argmax_v,
                                                      const int32_t *__restrict__ win, const int32_t *__restrict__ off,
-                                                     const int32_t *__restrict__ list, int C, int H, int W, int CB,
-                                                     float *__restrict__ grad_in)
+                                                     const int32_t *__restrict__ list_, int C, int H, int W, int CB,
+                                                     float *__restrict__ grad_in, int nident)
 {
+    struct List {                                             // list[i], or i itself
+        const int32_t *p;
+        __device__ __forceinline__ int operator[](int i) const { return IDENT ? i : p[i]; }
+    };
+    const List list{list_};
     extern __shared__ __attribute__((aligned(16))) float plane[];
     // argmax as the forward wrote it: int32, or uint16 (A16: half the index bytes; H*W <= 65535 always holds here)
     const int32_t *argmax = reinterpret_cast<const int32_t *>(argmax_v);
@@ -1068,7 +1075,7 @@ __global__ __launch_bounds__(NT) void k_roipool_bwd(const float *__restrict__ gr
     __syncthreads();
     // gridDim.z > 1 (few images): the image's RoI list is split over z, every part adds its LDS slice into a
     // pre-zeroed grad_in with global float atomics (contiguous 256-byte wave accesses)
-    const int rlo = off[b], rhi = off[b + 1];
+    const int rlo = IDENT ? 0 : off[b], rhi = IDENT ? nident : off[b + 1];
     const int rchunk = (rhi - rlo + (int)gridDim.z - 1) / (int)gridDim.z;
     const int r0 = min(rhi, rlo + (int)blockIdx.z * rchunk), r1 = min(rhi, r0 + rchunk);
     const int per = cb * RBINS;                      // contiguous elements per RoI for this channel slice
@@ -1409,14 +1416,6 @@ static int roipool_bwd(const float *grad_out, const void *argmax, bool a16, cons
         if (n == 0) return hipMemsetAsync(grad_in, 0, (size_t)B * C * HW * 4, st) == hipSuccess ? DG_OK : DG_EHIP;
         return dg_roipool_bwd_generic(grad_out, argmax, a16, win, n, B, C, H, W, PH, PW, mode, grad_in, st);
     }
-    if (B == 1) {
-        hipLaunchKernelGGL(k_roi_list_single, dim3((unsigned)dg_cdiv(n > 0 ? n : 1, 256)), dim3(256), 0, st, n, w.off, w.list);
-    } else {
-        if (hipMemsetAsync(w.cnt, 0, (size_t)B * 4, st) != hipSuccess) { dg_set_error("roipool_bwd: memset failed"); return DG_EHIP; }
-        if (n > 0) hipLaunchKernelGGL(k_roi_count, dim3((unsigned)dg_cdiv(n, 256)), dim3(256), 0, st, win, n, w.cnt);
-        hipLaunchKernelGGL(k_roi_scan, dim3(1), dim3(1024), 0, st, w.cnt, (int)B, w.off, w.cursor);
-        if (n > 0) hipLaunchKernelGGL(k_roi_fill, dim3((unsigned)dg_cdiv(n, 256)), dim3(256), 0, st, win, n, w.cursor, w.list);
-    }
     // channels per workgroup: as many as fit ~32 KiB of LDS, but keep >= ~1024 workgroups when possible
     int CB = 1;
     while (CB < 4 && (int64_t)CB * 2 * HW * 4 <= 32 * 1024 && CB * 2 <= C) CB *= 2;      // 4 channels: 16-byte vector path
@@ -1433,6 +1432,16 @@ static int roipool_bwd(const float *grad_out, const void *argmax, bool a16, cons
     //  103.5 us, 8 x 8 103.3, 16 x 8 105.7, and every other split count 121-136 us)
     int64_t S = 1;                                     // RoI-list splits when there are too few (image, slice) pairs
     while (S < 16 && B * dg_cdiv(C, CB) * S < 1024 && n / (B * S * 2) >= 64) S *= 2;
+    const bool ident = B == 1 && mode == DG_POOL_MAX && NT == 256;   // one image, max mode: the kernel takes the RoIs in order itself
+    if (ident) {
+    } else if (B == 1) {
+        hipLaunchKernelGGL(k_roi_list_single, dim3((unsigned)dg_cdiv(n > 0 ? n : 1, 256)), dim3(256), 0, st, n, w.off, w.list);
+    } else {
+        if (hipMemsetAsync(w.cnt, 0, (size_t)B * 4, st) != hipSuccess) { dg_set_error("roipool_bwd: memset failed"); return DG_EHIP; }
+        if (n > 0) hipLaunchKernelGGL(k_roi_count, dim3((unsigned)dg_cdiv(n, 256)), dim3(256), 0, st, win, n, w.cnt);
+        hipLaunchKernelGGL(k_roi_scan, dim3(1), dim3(1024), 0, st, w.cnt, (int)B, w.off, w.cursor);
+        if (n > 0) hipLaunchKernelGGL(k_roi_fill, dim3((unsigned)dg_cdiv(n, 256)), dim3(256), 0, st, win, n, w.cursor, w.list);
+    }
     dim3 grid((unsigned)dg_cdiv(C, CB), (unsigned)B, (unsigned)S);
     size_t lds = (size_t)CB * HW * 4;
     if (S > 1 && hipMemsetAsync(grad_in, 0, (size_t)B * C * HW * 4, st) != hipSuccess) { dg_set_error("roipool_bwd: memset failed"); return DG_EHIP; }
@@ -1440,13 +1449,18 @@ static int roipool_bwd(const float *grad_out, const void *argmax, bool a16, cons
     const bool vec = mode == DG_POOL_MAX && CB % 4 == 0 && C % CB == 0 && (((uintptr_t)grad_out) & 15) == 0 &&
                      (((uintptr_t)argmax) & (a16 ? 7 : 15)) == 0;
 #define BWD_LAUNCH(MODE, VEC, NT, A16) \
-    hipLaunchKernelGGL((k_roipool_bwd<MODE, VEC, NT, A16>), grid, dim3(NT), lds, st, grad_out, argmax, win, w.off, w.list, (int)C, (int)H, (int)W, CB, grad_in)
+    hipLaunchKernelGGL((k_roipool_bwd<MODE, VEC, NT, A16>), grid, dim3(NT), lds, st, grad_out, argmax, win, w.off, w.list, (int)C, (int)H, (int)W, CB, grad_in, 0)
+#define BWD_LAUNCH_IDENT(VEC, A16) \
+    hipLaunchKernelGGL((k_roipool_bwd<DG_POOL_MAX, VEC, 256, A16, true>), grid, dim3(256), lds, st, grad_out, argmax, win, w.off, w.list, (int)C, (int)H, (int)W, CB, grad_in, (int)n)
     if (mode == DG_POOL_MAX && vec && NT == 512) { if (a16) BWD_LAUNCH(DG_POOL_MAX, true, 512, true); else BWD_LAUNCH(DG_POOL_MAX, true, 512, false); }
     else if (mode == DG_POOL_MAX && vec && NT == 1024) { if (a16) BWD_LAUNCH(DG_POOL_MAX, true, 1024, true); else BWD_LAUNCH(DG_POOL_MAX, true, 1024, false); }
+    else if (ident && NT == 256 && vec) { if (a16) BWD_LAUNCH_IDENT(true, true); else BWD_LAUNCH_IDENT(true, false); }
+    else if (ident && NT == 256) { if (a16) BWD_LAUNCH_IDENT(false, true); else BWD_LAUNCH_IDENT(false, false); }
     else if (mode == DG_POOL_MAX && vec) { if (a16) BWD_LAUNCH(DG_POOL_MAX, true, 256, true); else BWD_LAUNCH(DG_POOL_MAX, true, 256, false); }
     else if (mode == DG_POOL_MAX) { if (a16) BWD_LAUNCH(DG_POOL_MAX, false, 256, true); else BWD_LAUNCH(DG_POOL_MAX, false, 256, false); }
     else BWD_LAUNCH(DG_POOL_AVG, false, 512, false);
 #undef BWD_LAUNCH
+#undef BWD_LAUNCH_IDENT
     DG_CHECK_LAUNCH("k_roipool_bwd");
     return DG_OK;
 }
