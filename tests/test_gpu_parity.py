@@ -113,8 +113,8 @@ def test_nms_band_reduce_forced_vs_oracle(va, oracle, dense, monkeypatch):
 def test_nms_small_image_rounds_and_serial_vs_oracle(va, oracle, fb, monkeypatch):
     """k_nms_resolve_small (images of 449 .. 4096 boxes: the non-zero mask words in LDS, the boxes decided in rounds): sparse
     and dense sets, ragged batches, both quirk settings, a chain that needs hundreds of rounds (so the round limit hands over to
-    the serial chain), a mask with more non-zero words than the LDS holds (ditto), and with DG_NMS_FORCE_FALLBACK=2 every
-    image through that in-kernel serial chain; against the oracle."""
+    the serial chain), masks with more non-zero words than the registers hold (the same rounds with the words streamed from
+    the mask), and with DG_NMS_FORCE_FALLBACK=2 every image through the in-kernel serial chain; against the oracle."""
     from vision_amd import ops
     monkeypatch.setenv("DG_NMS_FORCE_FALLBACK", fb)
     cases = []

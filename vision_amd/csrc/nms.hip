@@ -552,7 +552,9 @@ __global__ __launch_bounds__(T) void k_nms_reduce(const u64 *__restrict__ mask, 
 // 2000-box image); here ONE launch gathers the non-zero mask words of the image into LDS -- (row << 16 | word, bits), found
 // through the row summaries, every word's load in flight at once -- and then decides the boxes in ROUNDS like
 // k_nms_resolve_mc (see there), all entries in registers, the four bit sets in LDS: a round is two barriers.  More entries
-// than the LDS holds, or no end after max_rounds, and the serial chain over the dense mask finishes the image instead.
+// than that holds (8192: a 2000-box image at thr 0.3) and the rounds run with the words streamed from the mask instead (a
+// thread owns rows; 87 -> 54 us against the serial chain); no end after max_rounds, and the serial chain over the dense mask
+// finishes the image.
 #define RS_CAP 8192
 #define RS_PER (RS_CAP / 1024)
 __global__ __launch_bounds__(1024) void k_nms_resolve_small(const u64 *__restrict__ mask, const u64 *__restrict__ rsum,
@@ -618,7 +620,63 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_small(const u64 *__restric
         }
     }
     int rounds = 0;
-    bool bail = over;
+    bool bail = false;
+    if (over) {
+        // More non-zero words than the registers hold (a 2000-box image at thr 0.3): the same rounds with the words STREAMED --
+        // a thread owns the rows tid, tid + 1024, ... and loads their non-zero words from the mask (L2-resident, eight loads
+        // in flight) every time it needs them: once per round while the row is undecided, once more when it is kept.
+        u32 ralive = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = tid + 1024 * k;
+            bits[k] = (row < n) ? (bits[k] & ~((1ull << (row >> 6)) - 1ull)) : 0ull;
+            if (bits[k]) ralive |= 1u << k;
+        }
+        auto for_words = [&](int row, u64 b, auto &&fn) {       // fn(word index, mask word) for every set bit of b
+            const u64 *mrow = mask + (int64_t)row * W;
+            while (b) {
+                int wi[8];
+                u64 v[8];
+                int c = 0;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { wi[u] = 0; if (b) { wi[u] = __builtin_ctzll(b); b &= b - 1; c = u + 1; } }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = (u < c) ? mrow[wi[u]] : 0ull;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (u < c) fn(wi[u], v[u]);
+            }
+        };
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if ((ralive >> k) & 1u)
+                for_words(tid + 1024 * k, bits[k], [&](int w, u64 v) { if (v) atomicOr((unsigned long long *)&Bk[w], (unsigned long long)v); });
+        __syncthreads();
+        if (tid < 64) { K[tid] = valid & ~Bk[tid]; Bk[tid] = 0ull; }
+        for (;;) {
+            if (!__syncthreads_or(ralive != 0u)) break;
+            if (rounds >= max_rounds) { bail = true; break; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (!((ralive >> k) & 1u)) continue;
+                const int row = tid + 1024 * k;
+                const u64 rb = 1ull << (row & 63);
+                if (K[row >> 6] & rb) {
+                    for_words(row, bits[k], [&](int w, u64 v) {
+                        const u64 old = atomicOr((unsigned long long *)&R[w], (unsigned long long)v);
+                        if (old & v) atomicOr((unsigned long long *)&R2[w], (unsigned long long)(old & v));
+                    });
+                    ralive &= ~(1u << k);
+                } else if (R[row >> 6] & rb) {
+                    ralive &= ~(1u << k);
+                } else {
+                    for_words(row, bits[k], [&](int w, u64 v) { if (v) atomicOr((unsigned long long *)&Bk[w], (unsigned long long)v); });
+                }
+            }
+            __syncthreads();
+            if (tid < 64) { K[tid] |= valid & ~(K[tid] | R[tid] | Bk[tid]); Bk[tid] = 0ull; }
+            ++rounds;
+        }
+    }
     if (!over) {
         // round 0: boxes nothing suppresses are kept
 #pragma unroll
@@ -671,9 +729,19 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_small(const u64 *__restric
     if (quirk && total > 0) {                                    // uniform
         // yolo.py:196 `while ids_sorted.numel()>1`: the last kept box goes iff none of its own targets had only it as kept
         // suppressor (every other lower-ranked box was already removed by the kept boxes before it)
+        if (over) {
+            if (km >= 0 && (km & 1023) == tid) {                   // the thread that owns the last kept box's row
+                const int k = km >> 10;
+                const u64 *mrow = mask + (int64_t)km * W;
+                u64 b = bits[0];
+                if (k == 1) b = bits[1]; else if (k == 2) b = bits[2]; else if (k == 3) b = bits[3];
+                while (b) { const int w = __builtin_ctzll(b); b &= b - 1; atomicOr((unsigned long long *)&Bk[w], (unsigned long long)mrow[w]); }
+            }
+        } else {
 #pragma unroll
-        for (int q = 0; q < RS_PER; ++q)
-            if ((int)(key[q] >> 16) == km && tid + 1024 * q < E) atomicOr((unsigned long long *)&Bk[key[q] & 0xffffu], (unsigned long long)val[q]);
+            for (int q = 0; q < RS_PER; ++q)
+                if ((int)(key[q] >> 16) == km && tid + 1024 * q < E) atomicOr((unsigned long long *)&Bk[key[q] & 0xffffu], (unsigned long long)val[q]);
+        }
         __syncthreads();
         drop = !__syncthreads_or(tid < 64 && (Bk[tid] & ~R2[tid]) != 0ull);
     }
