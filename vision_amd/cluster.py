@@ -188,7 +188,8 @@ class _HipBackend:
         return h
 
     def results(self):
-        return (self.cent.cpu().numpy(), ops.kmeans_labels_i32(self.labels).cpu().numpy(), self.acc.cpu().numpy())
+        """centroids and accumulator on the host; the labels stay on the device (uint8) until somebody asks for them"""
+        return (self.cent.cpu().numpy(), self.labels, self.acc.cpu().numpy())
 
 
 class kmean:
@@ -212,7 +213,7 @@ class kmean:
         self._graphs = {}
         self.graph_state = "unused"             # "captured" / "eager: <why>" once the sharded loop has run
         self.cluster_centers_ = None
-        self.labels_ = None
+        self._labels_dev, self._labels_host = None, None
         self.n_iter_ = 0
         self.inertia_ = None
 
@@ -239,6 +240,25 @@ class kmean:
         X_all = np.asarray(X_all, np.float32)
         perm = np.random.RandomState(random_state).permutation(X_all.shape[0])
         return np.ascontiguousarray(X_all[perm[:k]]).copy()
+
+    # -- results --------------------------------------------------------------------------
+    @property
+    def labels_(self):
+        """int32 ndarray as sklearn's.  Widening 10 M labels and copying them to the host costs ten times the 30 Lloyd
+        iterations that produced them, so it happens on first access, not in fit(); the device tensor it is made from is
+        this fit's own (uint8, `labels_device_`).  None before the first fit."""
+        if self._labels_host is None and self._labels_dev is not None:
+            self._labels_host = ops.kmeans_labels_i32(self._labels_dev).cpu().numpy()
+        return self._labels_host
+
+    @labels_.setter
+    def labels_(self, value):
+        self._labels_host, self._labels_dev = value, None
+
+    @property
+    def labels_device_(self):
+        """this fit's labels where they were computed: uint8 tensor on the GPU (no copy)"""
+        return self._labels_dev
 
     # -- the fit --------------------------------------------------------------------------
     def fit(self, X, init_centers=None, fixed_iters=None):
@@ -269,7 +289,11 @@ class kmean:
             done += chunk
             n_iter = done
         cent, labels, acc = be.results()
-        self.cluster_centers_, self.labels_ = cent, labels
+        self.cluster_centers_ = cent
+        if isinstance(labels, torch.Tensor):
+            self._labels_dev, self._labels_host = labels, None
+        else:                                           # a stand-in backend (tests) hands over host labels
+            self._labels_dev, self._labels_host = None, np.asarray(labels)
         self.n_iter_ = n_iter
         self.inertia_ = float(acc[3 * k + 1]) / 4294967296.0
         return self

@@ -1646,6 +1646,23 @@ __global__ __launch_bounds__(256, 4) void k_nms_band(const float4 *__restrict__ 
         const float2 ar = bar[o + t * 64 + tid];
         rbox[tid] = b; rarea[tid] = ar.x; rrank[tid] = __float_as_int(ar.y) & 0xffff;
         int jend = (t * 64 + tid < n) ? (int)((u32)__float_as_int(ar.y) >> 16) : 0;   // last column tile that can hold a partner
+        // With the threshold known the band is narrower than the box: a partner q further right (x1_q >= x1_p) meets p in
+        // ix <= x2_p - x1_q, and IoU <= inter / max(A_p, A_q) <= (ix * h_p) / (w_p * h_p) = ix / w_p, so a pair over thr has
+        // x1_q <= x1_p + (1 - thr) * w_p: (1 - thr) of the candidates (half of them at 0.5, 0.3 at 0.7).  Float side: the
+        // reference's quotient exceeds ix / w_p by a few 2^-24 at most (every rounding in inter, the areas and the
+        // denominator, whose + 1e-7 only lowers it) -- covered by the 2e-4 added to (1 - thr) and the limit rounded up;
+        // boxes so thin that their area is not a normal number keep the full band (a box with w <= 0 or h <= 0 meets nobody:
+        // inter = 0).  Partners inside p's own bucket may start left of it: the limit's bucket includes that bucket.
+        if (t * 64 + tid < n) {
+            const float w = b.z - b.x, hh = b.w - b.y;
+            if (w > 1e-10f && hh > 1e-10f && w < 1e10f && hh < 1e10f) {
+                float xl = __builtin_fmaf(w, (1.0f - thr) + 2e-4f, b.x);
+                xl += fabsf(xl) * 0x1p-21f + 1e-37f;
+                xl = fminf(xl, b.z);
+                const int e2 = (start[(int64_t)img * (XB_G + 1) + xb_bucket(xl, h->xmin, h->scale) + 1] - 1) >> 6;
+                jend = e2 < jend ? e2 : jend;
+            }
+        }
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) jend = max(jend, __shfl_xor(jend, d, 64));
         if (tid == 0) s_jend = jend > t ? jend : t;
@@ -2029,6 +2046,235 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_mc(NmsHdr *__restrict__ hd
     if (g == 0 && tid == 0) { keep_count[img] = total - drop; h->fpdone = 1; h->rounds = rounds; h->npairs = Etot; }
 }
 
+// The same fixed point WITHOUT the per-round grid barrier (round 3, second form; the default).  Nothing in the rounds above
+// needs the workgroups in step: KEPT / REMOVED bits are final once set and a source that still looks undecided only keeps its
+// entry alive, so a workgroup may pass over its list whenever the sources' words it can see have changed, against whatever
+// the others have published by then.  Per pass: publish the own words (stores, not waited for), read all words (one trip),
+// the list pass; no arrival counter, no spin, no second trip for the snapshot -- two dependent trips to memory instead of
+// four, and a workgroup whose list is empty is finished whatever the others still do.  One grid-wide wait remains, at the
+// end: the keep list needs every workgroup's kept count.  A pass is only made when the snapshot differs from the last one
+// (own words included); otherwise the workgroup sleeps and polls again.  `max_rounds` counts list passes of one workgroup;
+// the first to exceed it (a ladder of boxes each suppressing the next) raises the image's bail flag and every workgroup
+// leaves the image to the serial chain, as before.  Which of the two an image takes can depend on timing; the keep list
+// does not.
+#define MC_ARR (MC_SLOT + 0)        // workgroups that are finished (or have given up)
+#define MC_BAIL (MC_SLOT + 1)       // 1: a workgroup ran out of rounds, 2: one stopped seeing progress
+#define MC_PASSES (MC_SLOT + 2)     // most list passes any workgroup made
+#define MC_IDLE_LIMIT (1 << 17)
+__global__ __launch_bounds__(1024) void k_nms_resolve_async(NmsHdr *__restrict__ hdr, const int32_t *__restrict__ counts, int64_t nmax,
+                                                            int64_t Np, int64_t W, int64_t lcap, int lsh, int64_t ecap,
+                                                            const int32_t *__restrict__ lcnt, const int32_t *__restrict__ order,
+                                                            u64 *__restrict__ maskws, u32 *__restrict__ mc, int max_rounds, int quirk,
+                                                            int64_t *__restrict__ keep, int32_t *__restrict__ keep_count)
+{
+    __shared__ NmsFpShared S;
+    const int img = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    NmsHdr *h = hdr + img;
+    lcnt += img * 64 * LC_STRIDE;
+    int Etot = lcnt[lane * LC_STRIDE];
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) Etot += __shfl_xor(Etot, d, 64);
+    if (h->mode != 0) {                                          // dense mask; if a pair list overflowed, say how many pairs there were
+        if (g == 0 && tid == 0) h->npairs = Etot;
+        return;
+    }
+    const int n = counts ? counts[img] : (int)nmax;
+    order += (int64_t)img * Np;
+    keep += (int64_t)img * nmax;
+    u32 *mcs = mc + (int64_t)img * MC_WORDS;
+    const u32 *list = (const u32 *)(maskws + (int64_t)img * Np * W) + (int64_t)g * lcap;       // 64 pair lists, then the 64 work lists
+    u32 *wlist = (u32 *)(maskws + (int64_t)img * Np * W) + (int64_t)(MC_G + g) * lcap;
+    u32 *wmine = wlist + 4 * tid;
+    const int E = lcnt[g * LC_STRIDE];                           // <= lcap (mode would be 1 otherwise)
+    const int own0 = g << lsh, ow0 = own0 >> 5, nown = (1 << lsh) >> 5;
+    if (tid < 32) { S.oK[tid] = 0u; S.oR[tid] = 0u; S.oR2[tid] = 0u; S.oBk[tid] = 0u; }
+    __syncthreads();
+    // round 0: boxes nothing suppresses are kept
+    for (int64_t c0 = 0; c0 * 4 < E; c0 += 8 * 1024) {
+        uint4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t c = c0 + u * 1024 + tid;
+            v[u] = (c * 4 < E) ? *(const uint4 *)(list + 4 * c) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int64_t e = (c0 + u * 1024 + tid) * 4;
+            if (e < E) atomicOr(&S.oBk[((v[u].x & 0xffffu) >> 5) - ow0], 1u << (v[u].x & 31u));
+            if (e + 1 < E) atomicOr(&S.oBk[((v[u].y & 0xffffu) >> 5) - ow0], 1u << (v[u].y & 31u));
+            if (e + 2 < E) atomicOr(&S.oBk[((v[u].z & 0xffffu) >> 5) - ow0], 1u << (v[u].z & 31u));
+            if (e + 3 < E) atomicOr(&S.oBk[((v[u].w & 0xffffu) >> 5) - ow0], 1u << (v[u].w & 31u));
+        }
+    }
+    __syncthreads();
+    if (tid < 32) { S.oK[tid] = (tid < nown ? nms_valid32(ow0 + tid, n) : 0u) & ~S.oBk[tid]; S.oBk[tid] = 0u; }
+    const u32 *src_list = list;
+    int mycnt = 0;
+    for (int64_t c = tid; c * 4 < E; c += 1024) mycnt += (E - c * 4 >= 4) ? 4 : (int)(E - c * 4);
+    int passes = 0, idle = 0;
+    bool bail = false, stuck = false, first = true;
+    for (;;) {
+        __syncthreads();                                           // the own words of the last pass are complete
+        if (tid < nown) { mc_st(&mcs[MC_K + ow0 + tid], S.oK[tid]); mc_st(&mcs[MC_R + ow0 + tid], S.oR[tid]); }
+        if (__syncthreads_or(mycnt != 0) == 0) break;              // the list is empty: every owned target is decided
+        if (passes >= max_rounds && Etot <= ecap) { bail = true; break; }
+        // what the others have published by now; the own words as they are here
+        int ch = first ? 1 : 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int w = tid + 1024 * q;
+            if (w < 2 * (int)W) {
+                const bool own = w >= ow0 && w < ow0 + nown;
+                const u32 k = own ? S.oK[w - ow0] : mc_ld(&mcs[MC_K + w]);
+                const u32 r = own ? S.oR[w - ow0] : mc_ld(&mcs[MC_R + w]);
+                ch |= (k != S.KR[2 * w]) | (r != S.KR[2 * w + 1]);
+                S.KR[2 * w] = k; S.KR[2 * w + 1] = r;
+            }
+        }
+        if (tid == 0) S.sngl = (int)mc_ld(&mcs[MC_BAIL]);           // somebody has given up: so does everybody
+        const int changed = __syncthreads_or(ch);
+        if (S.sngl) { bail = true; break; }
+        if (changed == 0) {                                        // nothing new: no pass
+            if (++idle > MC_IDLE_LIMIT) { stuck = true; break; }
+            __builtin_amdgcn_s_sleep(16);
+            continue;
+        }
+        first = false; idle = 0;
+        int out = 0;
+        const int nch = (mycnt + 3) >> 2;
+        for (int c0 = 0; c0 < nch; c0 += 8) {
+            uint4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[u] = (c0 + u < nch) ? *(const uint4 *)(src_list + 4 * (tid + 1024 * (c0 + u))) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                u32 key[16];
+                uint2 kr[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const uint4 vv = v[hh * 4 + (i >> 2)];
+                    key[i] = (i & 3) == 0 ? vv.x : ((i & 3) == 1 ? vv.y : ((i & 3) == 2 ? vv.z : vv.w));
+                    kr[i] = *(const uint2 *)&S.KR[2 * (key[i] >> 21)];
+                }
+                u32 old[16];                                     // the returning atomics of all 16 issued before the first is waited for
+                u32 applied = 0;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    old[i] = 0u;
+                    if ((c0 + hh * 4) * 4 + i >= mycnt) continue;
+                    const u32 src = key[i] >> 16, dst = (key[i] & 0xffffu) - (u32)own0;
+                    const u32 sb = 1u << (src & 31), db = 1u << (dst & 31);
+                    if (kr[i].x & sb) {
+                        old[i] = atomicOr(&S.oR[dst >> 5], db);
+                        applied |= 1u << i;
+                    } else if (!(kr[i].y & sb)) {
+                        atomicOr(&S.oBk[dst >> 5], db);
+                        wmine[((out >> 2) << 12) + (out & 3)] = key[i];
+                        ++out;
+                    }
+                }
+                if (applied) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        if (!((applied >> i) & 1u)) continue;
+                        const u32 dst = (key[i] & 0xffffu) - (u32)own0, db = 1u << (dst & 31);
+                        if (old[i] & db) atomicOr(&S.oR2[dst >> 5], db);
+                        else S.single[dst] = (unsigned short)(key[i] >> 16);
+                    }
+                }
+            }
+        }
+        mycnt = out;
+        src_list = wlist;
+        __syncthreads();
+        if (tid < 32) {                                            // what nothing blocks is kept
+            S.oK[tid] |= (tid < nown ? nms_valid32(ow0 + tid, n) : 0u) & ~(S.oK[tid] | S.oR[tid] | S.oBk[tid]);
+            S.oBk[tid] = 0u;
+        }
+        ++passes;
+    }
+    // ---- finished (the final words went out at the top of the last turn), out of rounds, or stuck: tell the others, wait for all
+    if (tid == 0) S.sngl = 0;
+    __syncthreads();
+    if (!bail && !stuck) {
+        int v = 0;                                                 // one owned target per thread: its sole suppressor
+        if (tid < (1 << lsh) && ((S.oR[tid >> 5] & ~S.oR2[tid >> 5]) >> (tid & 31)) & 1u) v = (int)S.single[tid] + 1;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, 64));
+        if (lane == 0 && v) atomicMax(&S.sngl, v);
+    }
+    __syncthreads();
+    if (wave == 1) {
+        const u32 kw = lane < nown ? S.oK[lane] : 0u;
+        int kc = __builtin_popcount(kw), km = kw ? (ow0 + lane) * 32 + 32 - __builtin_clz(kw) : 0;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { kc += __shfl_xor(kc, d, 64); km = max(km, __shfl_xor(km, d, 64)); }
+        if (lane == 0) {
+            mc_st(&mcs[MC_KCNT + g], (u32)kc); mc_st(&mcs[MC_KMAX + g], (u32)km); mc_st(&mcs[MC_SNGL + g], (u32)S.sngl);
+            if (bail || stuck) atomicMax(&mcs[MC_BAIL], stuck ? 2u : 1u);
+            atomicMax(&mcs[MC_PASSES], (u32)passes);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // what this thread published has arrived
+    __syncthreads();
+    if (tid == 0) {
+        atomicAdd(&mcs[MC_ARR], 1u);
+        u32 spins = 0;
+        int ok = 1;
+        while (mc_ld(&mcs[MC_ARR]) < (u32)MC_G) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > MC_SPIN_LIMIT) { ok = 0; break; }
+        }
+        const u32 b = mc_ld(&mcs[MC_BAIL]);
+        S.ok = (ok && b != 2u) ? 1 : 0;
+        S.live = (unsigned long long)b;
+        S.cnt[3] = (int)mc_ld(&mcs[MC_PASSES]);
+    }
+    __syncthreads();
+    const int rounds = S.cnt[3];
+    if (!S.ok) {                                                  // a workgroup never arrived, or one stopped seeing progress
+        if (g == 0 && tid == 0) {
+            if (Etot <= ecap) { h->fpdone = 0; }                  // the serial chain does this image
+            else { h->fpdone = 1; keep_count[img] = -1; }
+            h->rounds = -1; h->npairs = Etot;
+        }
+        return;
+    }
+    if (S.live != 0ull) {                                         // uniform over the grid: k_nms_reduce_csr<SEG> does this image from scratch
+        if (g == 0 && tid == 0) { h->fpdone = 0; h->rounds = rounds; h->npairs = Etot; }
+        return;
+    }
+    __syncthreads();
+    // ---- the kept set is final and every workgroup's counts are out: keep list in rank order, each workgroup its targets
+    if (wave == 0) {
+        int kc = (int)mc_ld(&mcs[MC_KCNT + lane]), km = (int)mc_ld(&mcs[MC_KMAX + lane]), sg = (int)mc_ld(&mcs[MC_SNGL + lane]);
+        int incl = kc;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) { km = max(km, __shfl_xor(km, d, 64)); sg = max(sg, __shfl_xor(sg, d, 64)); }
+        const int total = __shfl(incl, 63, 64), mybase = __shfl(incl - kc, g, 64);
+        const u32 kw = lane < nown ? S.oK[lane] : 0u;            // word offsets of this workgroup's kept bits
+        int wi = __builtin_popcount(kw);
+        const int wc = wi;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(wi, d, 64); if (lane >= d) wi += up; }
+        if (lane < 32) S.off[lane] = mybase + wi - wc;
+        if (lane == 0) { S.cnt[0] = total; S.cnt[1] = km; S.cnt[2] = sg; }
+    }
+    __syncthreads();
+    const int total = S.cnt[0], km = S.cnt[1] - 1;                 // km: the last kept box (-1: none)
+    const int drop = (quirk && total > 0 && S.cnt[2] - 1 != km) ? 1 : 0;
+    if (tid < (1 << lsh)) {
+        const int t = own0 + tid;
+        const u32 kw = S.oK[tid >> 5];
+        if (((kw >> (tid & 31)) & 1u) && !(drop && t == km))
+            keep[S.off[tid >> 5] + __builtin_popcount(kw & ((1u << (tid & 31)) - 1u))] = (int64_t)order[t];
+    }
+    if (g == 0 && tid == 0) { keep_count[img] = total - drop; h->fpdone = 1; h->rounds = rounds; h->npairs = Etot; }
+}
+
 // ---------------------------------------------------------------- host
 extern "C" size_t dg_nms_workspace_bytes(int64_t batch, int64_t nmax)
 {
@@ -2184,8 +2430,13 @@ static int nms_phase_reduce(const int32_t *counts, int64_t batch, int64_t nmax, 
         hdr = w.hdr;
         // (the mask phase's k_nms_band zeroed w.mc; the reduce phase run again on its own -- bench.py times it so -- does it itself)
         if (standalone && hipMemsetAsync(w.mc, 0, (size_t)batch * MC_WORDS * 4, st) != hipSuccess) { dg_set_error("nms_reduce: memset failed"); return DG_EHIP; }
-        hipLaunchKernelGGL(k_nms_resolve_mc, dim3(MC_G, (unsigned)batch), dim3(1024), 0, st, w.hdr, counts, nmax, w.Np, w.W, w.lcap, w.lsh,
-                           w.ecap, w.lcnt, w.order, w.mask, w.mc, nms_fp_rounds(), quirk_drop_last, keep, keep_count);
+        // DG_NMS_FP_SYNC=1: the fixed point with a grid barrier per round (k_nms_resolve_mc) instead of the free-running one
+        if (getenv("DG_NMS_FP_SYNC") && atoi(getenv("DG_NMS_FP_SYNC")) == 1)
+            hipLaunchKernelGGL(k_nms_resolve_mc, dim3(MC_G, (unsigned)batch), dim3(1024), 0, st, w.hdr, counts, nmax, w.Np, w.W, w.lcap, w.lsh,
+                               w.ecap, w.lcnt, w.order, w.mask, w.mc, nms_fp_rounds(), quirk_drop_last, keep, keep_count);
+        else
+            hipLaunchKernelGGL(k_nms_resolve_async, dim3(MC_G, (unsigned)batch), dim3(1024), 0, st, w.hdr, counts, nmax, w.Np, w.W, w.lcap, w.lsh,
+                               w.ecap, w.lcnt, w.order, w.mask, w.mc, nms_fp_rounds(), quirk_drop_last, keep, keep_count);
         hipLaunchKernelGGL(k_nms_reduce_csr<true>, dim3((unsigned)batch), dim3(1024), 0, st, w.mask, w.order, counts, nmax, w.Np,
                            w.W, w.ecap, (const int32_t *)nullptr, (const int32_t *)nullptr, w.ekey, w.eval, quirk_drop_last, keep, keep_count,
                            w.hdr, w.diag, w.lcnt, w.lcap);
