@@ -1622,6 +1622,7 @@ __global__ __launch_bounds__(256, 4) void k_nms_band(const float4 *__restrict__ 
     __shared__ float4 rbox[64];
     __shared__ float rarea[64];
     __shared__ int rrank[64];
+    __shared__ int s_jrow[64], s_rpos[64], s_jtmp[64];             // per row slot: last column tile of its band, its place in the tile
     __shared__ int s_jend;
     __shared__ u32 s_stage[4][BAND_STAGE];                         // a wave's pairs wait here: one bump of the list cursors per flush
     __shared__ int s_ocnt[4][64], s_obase[4][64];
@@ -1644,8 +1645,7 @@ __global__ __launch_bounds__(256, 4) void k_nms_band(const float4 *__restrict__ 
     if (tid < 64) {
         const float4 b = bbox[o + t * 64 + tid];
         const float2 ar = bar[o + t * 64 + tid];
-        rbox[tid] = b; rarea[tid] = ar.x; rrank[tid] = __float_as_int(ar.y) & 0xffff;
-        int jend = (t * 64 + tid < n) ? (int)((u32)__float_as_int(ar.y) >> 16) : 0;   // last column tile that can hold a partner
+        int jend = (t * 64 + tid < n) ? (int)((u32)__float_as_int(ar.y) >> 16) : -1;  // last column tile that can hold a partner
         // With the threshold known the band is narrower than the box: a partner q further right (x1_q >= x1_p) meets p in
         // ix <= x2_p - x1_q, and IoU <= inter / max(A_p, A_q) <= (ix * h_p) / (w_p * h_p) = ix / w_p, so a pair over thr has
         // x1_q <= x1_p + (1 - thr) * w_p: (1 - thr) of the candidates (half of them at 0.5, 0.3 at 0.7).  Float side: the
@@ -1663,12 +1663,23 @@ __global__ __launch_bounds__(256, 4) void k_nms_band(const float4 *__restrict__ 
                 jend = e2 < jend ? e2 : jend;
             }
         }
+        // The rows of the tile in the order of their bands, longest first (their order inside the tile is free: a row carries
+        // its rank and its place): column tile j then needs the first R_j row slots only, those whose band reaches it -- a
+        // tile's bands differ by the boxes' widths, and running all 64 rows to the end of the widest cost 1.8 x the pairs.
+        s_jtmp[tid] = jend;
+        int slot = 0;
+#pragma unroll 8
+        for (int k = 0; k < 64; ++k) { const int jk = s_jtmp[k]; slot += (jk > jend || (jk == jend && k < tid)) ? 1 : 0; }
+        rbox[slot] = b; rarea[slot] = ar.x; rrank[slot] = __float_as_int(ar.y) & 0xffff;
+        s_jrow[slot] = jend; s_rpos[slot] = tid;
+        int jmax = jend;
 #pragma unroll
-        for (int d = 32; d > 0; d >>= 1) jend = max(jend, __shfl_xor(jend, d, 64));
-        if (tid == 0) s_jend = jend > t ? jend : t;
+        for (int d = 32; d > 0; d >>= 1) jmax = max(jmax, __shfl_xor(jmax, d, 64));
+        if (tid == 0) s_jend = jmax > t ? jmax : t;
     }
     __syncthreads();
     const int jend = s_jend;
+    const int myjrow = s_jrow[lane], myrpos = s_rpos[lane];
     const float2 *cbar = bar + o;
     u32 *stage = s_stage[wave];
     int staged = 0;                                                // wave-uniform
@@ -1712,24 +1723,35 @@ __global__ __launch_bounds__(256, 4) void k_nms_band(const float4 *__restrict__ 
         const float cx1 = cb.x, cy1 = cb.y, cx2 = cb.z, cy2 = cb.w;
         u32 wlo = 0, whi = 0;
         u64 ambany = 0;
+        // row slots whose band reaches this column tile (the tile's own diagonal tile: all of them)
+        const int R = (j == t) ? 64 : __builtin_popcountll(__ballot(myjrow >= j));
+#pragma unroll 1
+        for (int r0 = 0; r0 < R; r0 += 8) {
 #pragma unroll
-        for (int r = 0; r < 64; ++r) {
-            const float4 p = rbox[r];
-            const float ix = vmax(vmin(p.z, cx2) - vmax(p.x, cx1), 0.0f);
-            const float iy = vmax(vmin(p.w, cy2) - vmax(p.y, cy1), 0.0f);
-            const float inter = ix * iy;
-            const float den = ((rarea[r] + ca) - inter) + 1e-7f;
-            const float e1 = __builtin_fmaf(-thr, den, inter), e2 = __builtin_fmaf(-thr_below, den, inter);
-            const u64 bal = __ballot(!(e1 < 0.0f));
-            ambany |= __ballot(e2 > 0.0f) & ~bal;
-            asm("v_writelane_b32 %0, %1, %2" : "+v"(wlo) : "s"((u32)bal), "n"(r));
-            asm("v_writelane_b32 %0, %1, %2" : "+v"(whi) : "s"((u32)(bal >> 32)), "n"(r));
+            for (int u = 0; u < 8; ++u) {
+                const int r = r0 + u;                              // (slots past R in the last eight: tested too, harmless)
+                const float4 p = rbox[r];
+                const float ix = vmax(vmin(p.z, cx2) - vmax(p.x, cx1), 0.0f);
+                const float iy = vmax(vmin(p.w, cy2) - vmax(p.y, cy1), 0.0f);
+                const float inter = ix * iy;
+                const float den = ((rarea[r] + ca) - inter) + 1e-7f;
+                const float e1 = __builtin_fmaf(-thr, den, inter), e2 = __builtin_fmaf(-thr_below, den, inter);
+                const u64 bal = __ballot(!(e1 < 0.0f));
+                ambany |= __ballot(e2 > 0.0f) & ~bal;
+                // (lane select through m0: an instruction takes one SGPR beside it; nothing else in this kernel uses m0, and the
+                // compiler, which reserves it, only notes that the clobber names a reserved register)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"
+                asm("s_mov_b32 m0, %3\n\tv_writelane_b32 %0, %2, m0\n\tv_writelane_b32 %1, %4, m0"
+                    : "+v"(wlo), "+v"(whi) : "s"((u32)bal), "s"(r), "s"((u32)(bal >> 32)) : "m0");
+#pragma clang diagnostic pop
+            }
         }
-        u64 myword = ((u64)whi << 32) | wlo;                       // lane = row, bit = column of this tile
+        u64 myword = ((u64)whi << 32) | wlo;                       // lane = row slot, bit = column of this tile
         if (ambany) {                                             // rare: a quotient within one ulp of thr somewhere
             u64 w2 = 0;
 #pragma unroll 2
-            for (int r = 0; r < 64; ++r) {
+            for (int r = 0; r < ((R + 7) & ~7); ++r) {
                 const float4 p = rbox[r];
                 const float ix = fmaxf(fminf(p.z, cx2) - fmaxf(p.x, cx1), 0.0f);
                 const float iy = fmaxf(fminf(p.w, cy2) - fmaxf(p.y, cy1), 0.0f);
@@ -1740,7 +1762,7 @@ __global__ __launch_bounds__(256, 4) void k_nms_band(const float4 *__restrict__ 
             }
             myword = w2;
         }
-        if (j == t) myword &= ~((2ull << lane) - 1ull);            // later positions only: every pair once
+        if (j == t) myword &= ~((2ull << myrpos) - 1ull);          // later positions only: every pair once
         const int cnt = __builtin_popcountll(myword);
         if (__ballot(cnt != 0)) {                                  // wave-uniform
             int incl = cnt;
