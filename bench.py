@@ -367,7 +367,7 @@ def extra_stress(d, n=65536):
             a_n = 20.0 * n + n * n / 4.0 + 8.0 * kept            # A(N) = 20 N + N^2/8 written + N^2/8 read + 8 K
             r[tag] = {"sort_ms": t_sort, "mask_ms": t_mask, "reduce_ms": t_red, "whole_call_ms": t_all, "kept": kept,
                       "boxes_per_s": n / t_all * 1e3,
-                      "path": ("pruned: x-bucket band pair search + fixed-point keep list on 64 workgroups" if mode == 0 else "dense mask"),
+                      "path": ("pruned: x-bucket band pair search (band narrowed by the threshold) + free-running fixed-point keep list on 64 workgroups" if mode == 0 else "dense mask"),
                       "fixed_point_rounds": rounds if mode == 0 and fpdone else None, "suppressing_pairs": npairs if mode == 0 else None,
                       "candidates_per_box": cpb, "estimated_pairs_per_box": est,
                       "survey_A_N_frac": a_n / (t_all * 1e-3) / 1e9 / HBM_PEAK_GBPS,

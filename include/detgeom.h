@@ -96,7 +96,7 @@ int dg_nms_phase_reduce(const int32_t *counts, int64_t batch, int64_t nmax, int 
 
 /* diagnostic (synchronous): which path image `img` of the LAST call on this workspace took.  out6 (host, 6 ints):
  * [0] 0 = pruned pair search (x-bucket band, no N x N mask), 1 = dense mask; [1] 1 = the fixed-point keep-list kernel
- * finished the image, 0 = a serial reduce did; [2] rounds of the fixed point (-1: its grid barrier timed out); [3] suppressing
+ * finished the image, 0 = a serial reduce did; [2] rounds of the fixed point (most list passes of one workgroup; -1: its workgroups never all arrived); [3] suppressing
  * pairs found; [4] candidate pairs per box as estimated before the search; [5] suppressing pairs per box as estimated from
  * 1024 sampled boxes.  No counterpart in the reference. */
 int dg_nms_path_info(const void *ws, size_t ws_bytes, int64_t batch, int64_t nmax, int64_t img, int32_t *out6_host);

@@ -184,6 +184,48 @@ def test_nms_pruned_path_vs_oracle(va, oracle, prune, rounds, monkeypatch):
                     assert cnt[i] == len(want) and np.array_equal(keep[i, :cnt[i]], want), (boxes.shape, thr, quirk, i, info)
 
 
+def test_nms_band_narrowed_by_threshold_vs_oracle(va, oracle, monkeypatch):
+    """k_nms_band only looks at partners whose left edge lies within (1 - thr) of a box's width (IoU <= ix / w): sets where that
+    limit is delicate -- coordinates far from the origin (the limit's rounding), boxes too thin for a normal area (full band
+    kept), thresholds close to 0 and to 1, exactly 1 and above, exact IoU values of the set, everything in one x-bucket, integer
+    grids with many equal left edges, inverted boxes; the pruned path forced (DG_NMS_PRUNE=2) and free; against the oracle."""
+    from vision_amd import ops
+    rng = np.random.default_rng(77)
+    n = 5200
+    sets = []
+    b0, s0 = wl.stress_boxes(91, n, dense=True)
+    sets.append(("dense", b0, s0))
+    far = b0.copy(); far[:, [0, 2]] += np.float32(4096.0); far[:, [1, 3]] -= np.float32(300.0)
+    sets.append(("far from the origin", far, s0))
+    thin = wl.stress_boxes(92, n, dense=False)[0].copy()
+    thin[::3, 2] = thin[::3, 0] + np.float32(1e-12); thin[1::3, 3] = thin[1::3, 1] + np.float32(1e-30)
+    sets.append(("thin", thin, s0))
+    xy = rng.integers(0, 60, (n, 2)).astype(np.float32); wh = rng.integers(1, 12, (n, 2)).astype(np.float32)
+    grid = np.concatenate([xy, xy + wh], 1)
+    sets.append(("integer grid", grid, s0))
+    one = b0.copy(); one[:, 0] = np.float32(0.25); one[:, 2] = one[:, 0] + rng.uniform(0.01, 0.3, n).astype(np.float32)
+    sets.append(("one left edge", one, s0))
+    inv = wl.random_boxes(93, n).copy(); inv[::7] = inv[::7][:, [2, 1, 0, 3]]; inv[3::11] = inv[3::11][:, [0, 3, 2, 1]]
+    sets.append(("inverted", inv, s0))
+    near = b0[rng.integers(0, 400, n)] + rng.uniform(-0.004, 0.004, (n, 4)).astype(np.float32)      # heavy clusters of near-duplicates
+    sets.append(("near-duplicates", near.astype(np.float32), s0))
+    for prune in ("2", "1"):
+        monkeypatch.setenv("DG_NMS_PRUNE", prune)
+        for name, b, s in sets:
+            vals = np.unique(oracle.iou_pairwise(b[:48], b[:512]))
+            vals = vals[(vals > 0.02) & (vals < 1)]
+            thrs = [0.05, 0.5, 0.7, 0.95, 0.999, 1.0, 1.5]
+            if len(vals):
+                v = vals[rng.integers(0, len(vals))]
+                thrs += [float(v), float(np.nextafter(v, np.float32(2)))]
+            bt, st = torch.from_numpy(b)[None].cuda(), torch.from_numpy(s)[None].cuda()
+            for thr in thrs:
+                keep, cnt = ops.nms_batched(bt, st, None, thr, True)
+                got = keep[0, :int(cnt[0])].cpu().numpy()
+                want = oracle.nms(b, s, thr, True)
+                assert np.array_equal(got, want), (name, prune, thr, ops.nms_path_info(bt.device, 1, n), got.size, len(want))
+
+
 def test_nms_threshold_edges_vs_oracle(va, oracle):
     """The mask phase tests inter/den < thr without dividing: thresholds that are exactly an IoU value of the set,
     its float neighbours, 0, negatives, inf and NaN must all give the oracle's (dividing) answer."""

@@ -111,10 +111,10 @@ def nms(out_box, out_score, threshold=0.1):
     scores = torch.as_tensor(out_score)
     keep, cnt = ops.nms_batched(boxes.reshape(1, -1, 4), scores.reshape(1, -1), None, threshold, True)
     k = int(cnt[0].item())
-    if k < 0:           # the pruned path's grid barrier timed out with more pairs than its serial fallback holds (nms.hip)
+    if k < 0:           # the pruned path's 64 workgroups never all arrived, with more pairs than its serial fallback holds (nms.hip)
         from ._abi import DetGeomError
         raise DetGeomError("nms: the keep list was not produced (keep_count = -1): the GPU did not run the 64 workgroups of "
-                               "k_nms_resolve_mc together; set DG_NMS_PRUNE=0 to take the dense-mask path")
+                               "the fixed-point kernel together; set DG_NMS_PRUNE=0 to take the dense-mask path")
     return _back(keep[0, :k], dev_in)
 
 
