@@ -188,6 +188,9 @@ class _HipBackend:
         return h
 
     def results(self):
+        return (self.cent.cpu().numpy(), ops.kmeans_labels_i32(self.labels).cpu().numpy(), self.acc.cpu().numpy())
+
+    def results_lazy(self):
         """centroids and accumulator on the host; the labels stay on the device (uint8) until somebody asks for them"""
         return (self.cent.cpu().numpy(), self.labels, self.acc.cpu().numpy())
 
@@ -288,7 +291,7 @@ class kmean:
                     break
             done += chunk
             n_iter = done
-        cent, labels, acc = be.results()
+        cent, labels, acc = be.results_lazy() if hasattr(be, "results_lazy") else be.results()
         self.cluster_centers_ = cent
         if isinstance(labels, torch.Tensor):
             self._labels_dev, self._labels_host = labels, None

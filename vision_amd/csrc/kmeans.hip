@@ -433,6 +433,20 @@ __global__ __launch_bounds__(256) void k_labels_widen(const uint8_t *__restrict_
     for (; i < n; i += stride) out[i] = l[i];
 }
 
+// Zeroes small buffers of 64-bit words (the partial-sums buffers of the loops below).  A kernel, not hipMemsetAsync: captured in a HIP graph (ROCm 7.2) the memset node of
+// this chunk was not carried out again on the graph's SECOND replay when the device had been synchronised between the eager
+// run and the capture -- the buffers kept the previous replay's sums and the centroids collapsed
+// (test_kmeans_sharded_loop_library_comm_vs_oracle found it once a fit stopped copying its labels to the host).
+__global__ void k_km_zero(long long *__restrict__ p, int n)
+{
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0;
+}
+
+static inline void km_zero(void *p, size_t bytes, hipStream_t st)          // bytes: a multiple of 8
+{
+    hipLaunchKernelGGL(k_km_zero, dim3(bytes > 65536 ? 16 : 1), dim3(256), 0, st, (long long *)p, (int)(bytes / 8));
+}
+
 static inline int km_kmax(int64_t k) { return k <= 5 ? 5 : (k <= 9 ? 9 : 16); }
 // One resident round: as many workgroups as the device holds at once for this variant (registers and LDS decide),
 // so that no workgroup starts on a mostly idle chip after the others have finished.
@@ -526,7 +540,7 @@ extern "C" int dg_kmeans_iou_step(const float *wh, int64_t n, const float *cent,
     hipStream_t st = (hipStream_t)s;
     int64_t *part = (int64_t *)ws;
     // the workspace arrives with arbitrary contents
-    if (hipMemsetAsync(part, 0, dg_kmeans_part_elems(k) * 8, st) != hipSuccess) { dg_set_error("kmeans_step: memset failed"); return DG_EHIP; }
+    km_zero(part, dg_kmeans_part_elems(k) * 8, st);
     if ((rc = km_launch(wh, n, const_cast<float *>(cent), k, labels, nullptr, part, nullptr, nullptr, 0, true, st))) return rc;
     return km_finish(part, k, nullptr, acc, nullptr, 0, st);
 }
@@ -565,7 +579,7 @@ extern "C" int dg_kmeans_iou_run(const float *wh, int64_t n, float *cent, int64_
     hipStream_t st = (hipStream_t)s;
     const size_t pe = dg_kmeans_part_elems(k);
     int64_t *part[3] = {(int64_t *)ws, (int64_t *)ws + pe, (int64_t *)ws + 2 * pe};
-    if (hipMemsetAsync(ws, 0, 3 * pe * 8, st) != hipSuccess) { dg_set_error("kmeans_run: memset failed"); return DG_EHIP; }
+    km_zero(ws, 3 * pe * 8, st);
     for (int64_t t = 0; t < iters; ++t) {
         // launch t: centroids <- sums of t-1 (and history[slot0+t-1]); adds into buffer t%3; zeroes buffer (t+1)%3
         rc = km_launch(wh, n, cent, k, labels, t ? part[(t - 1) % 3] : nullptr, part[t % 3], part[(t + 1) % 3], history, slot0 + t - 1,
@@ -581,7 +595,7 @@ static int km_sharded_issue(dg_comm_t *c, const float *wh, int64_t n, float *cen
 {
     const size_t pe = dg_kmeans_part_elems(k);
     int64_t *part[3] = {(int64_t *)ws, (int64_t *)ws + pe, (int64_t *)ws + 2 * pe};
-    if (hipMemsetAsync(ws, 0, 3 * pe * 8, st) != hipSuccess) { dg_set_error("kmeans_run_sharded: memset failed"); return DG_EHIP; }
+    km_zero(ws, 3 * pe * 8, st);
     int rc;
     for (int64_t t = 0; t < iters; ++t) {
         // same rotation as dg_kmeans_iou_run; the buffer launch t added into is summed over the ranks before launch t+1 folds it
@@ -1311,7 +1325,7 @@ extern "C" int dg_kmeans_iou_run_prepared(const float *wh, int64_t n, float *cen
     KcWs w = kc_layout(n, k, ws);
     const size_t pe = dg_kmeans_part_elems(k);
     // four buffers: three in rotation for the cell iterations (as dg_kmeans_iou_run), the fourth for the box-order pass
-    if (hipMemsetAsync(w.part[0], 0, (size_t)((char *)w.part[3] - (char *)w.part[0]) + pe * 8, st) != hipSuccess) { dg_set_error("kmeans_run_prepared: memset failed"); return DG_EHIP; }
+    km_zero(w.part[0], (size_t)((char *)w.part[3] - (char *)w.part[0]) + pe * 8, st);
     // default: one launch per cell iteration (k_kc_iter); DG_KMEANS_PERSIST=1: all of them in one launch (k_kc_persist, a grid
     // barrier per iteration -- measured slower on this part, see DESIGN.md: kept for the measurement and as the structure a
     // peer-mapped exchange between GPUs would need)
@@ -1328,7 +1342,7 @@ extern "C" int dg_kmeans_iou_run_prepared(const float *wh, int64_t n, float *cen
         if (getenv("DG_KMEANS_PERSIST_G") && atoi(getenv("DG_KMEANS_PERSIST_G")) > 0 && atoi(getenv("DG_KMEANS_PERSIST_G")) < G) G = atoi(getenv("DG_KMEANS_PERSIST_G"));
         if ((w.pmax + G - 1) / G <= KM_BLOCK) {                       // a piece per thread at most
             unsigned *bar = (unsigned *)&w.hdr->pad[1];
-            if (hipMemsetAsync(&w.hdr->pad[0], 0, 16, st) != hipSuccess) { dg_set_error("kmeans_run_prepared: memset failed"); return DG_EHIP; }
+            km_zero(&w.hdr->pad[0], 16, st);
 #define KC_PERSIST(KM, FULL)                                                                                                       \
             hipLaunchKernelGGL((k_kc_persist<KM, FULL>), dim3((unsigned)G), dim3(KM_BLOCK), 0, st, w.hdr, w.swh, w.slab, w.plab, w.pstart, \
                                w.pcnt, w.psum, w.pbox, cent, (int)k, w.part[0], w.part[1], w.part[2], (long long *)history, slot0,       \
