@@ -218,32 +218,70 @@ __global__ __launch_bounds__(256) void k_bitonic_global(u64 *__restrict__ keys, 
 __global__ __launch_bounds__(1024) void k_nms_sort_chunks(const float *__restrict__ scores, const int32_t *__restrict__ counts,
                                                           int64_t nmax, int64_t Np2, u64 *__restrict__ keys)
 {
-    __shared__ u64 s[SORT_CHUNK];
+    // Round 3, second form: the keys live in REGISTERS, four consecutive ones per thread (element 4 tid + r).  Of the 78
+    // compare-exchange steps of the bitonic network, 23 have their partner in the same thread (j = 1, 2: no data movement),
+    // 45 in the same wave (j = 4 .. 128 elements = 1 .. 32 lanes: a cross-lane exchange), and only 10 cross waves
+    // (j >= 256: through LDS, two workgroup barriers each).  The LDS version before it made every step a round trip of
+    // reads and conditional writes (15 of them with a barrier) and took 31 us for 64 k keys on its 16 workgroups.
+    __shared__ __attribute__((aligned(16))) u64 s[SORT_CHUNK];
     const int tid = threadIdx.x, img = blockIdx.y;
     const int n = counts ? counts[img] : (int)nmax;
     const int64_t base = (int64_t)blockIdx.x * SORT_CHUNK;
     u64 *g = keys + (int64_t)img * Np2 + base;
-    for (int i = tid; i < SORT_CHUNK; i += 1024) s[i] = (base + i < n) ? make_key(scores[(int64_t)img * nmax + base + i], (u32)(base + i)) : ~0ull;
-    // (wave-local steps without workgroup barriers: see k_nms_sort_small)
-    bool crossed = true;
-    for (int k = 2; k <= SORT_CHUNK; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            const bool cross = j >= 128;
-            if (cross || crossed) __syncthreads();
-            else __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    u64 v[4];
 #pragma unroll
-            for (int q = 0; q < SORT_CHUNK / 2 / 1024; ++q) {
-                const int t = tid + 1024 * q;
-                const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1)), l = i | j;
-                const u64 a = s[i], b = s[l];
-                const bool asc = (i & k) == 0;                 // k = SORT_CHUNK: ascending throughout
-                if ((a > b) == asc) { s[i] = b; s[l] = a; }
+    for (int r = 0; r < 4; ++r) {
+        const int64_t i = base + 4 * tid + r;
+        v[r] = (i < n) ? make_key(scores[(int64_t)img * nmax + i], (u32)i) : ~0ull;
+    }
+    // element i keeps the smaller key of its pair iff it is the lower element of an ascending pair or the upper of a descending one
+    auto keep = [](u64 mine, u64 other, bool takemin) { return ((other < mine) == takemin) ? other : mine; };
+    const int e0 = 4 * tid;
+#pragma unroll 1
+    for (int k = 2; k <= SORT_CHUNK; k <<= 1) {
+#pragma unroll 1
+        for (int j = k >> 1; j >= 256; j >>= 1) {                   // partners in other waves
+            __syncthreads();                                         // (the reads of the step before are done)
+            *(uint4 *)&s[e0] = make_uint4((u32)v[0], (u32)(v[0] >> 32), (u32)v[1], (u32)(v[1] >> 32));
+            *(uint4 *)&s[e0 + 2] = make_uint4((u32)v[2], (u32)(v[2] >> 32), (u32)v[3], (u32)(v[3] >> 32));
+            __syncthreads();
+            const int p0 = e0 ^ j;
+            const uint4 a = *(const uint4 *)&s[p0], b = *(const uint4 *)&s[p0 + 2];
+            const u64 o[4] = {((u64)a.y << 32) | a.x, ((u64)a.w << 32) | a.z, ((u64)b.y << 32) | b.x, ((u64)b.w << 32) | b.z};
+            const bool takemin = ((e0 & j) == 0) == ((e0 & k) == 0);   // (j, k >= 256: the same for the thread's four elements)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = keep(v[r], o[r], takemin);
+        }
+#pragma unroll 1
+        for (int j = (k >> 1) < 128 ? (k >> 1) : 128; j >= 4; j >>= 1) {   // partners in other lanes of this wave
+            const int d = j >> 2;
+            const bool takemin = ((e0 & j) == 0) == ((e0 & k) == 0);   // (j >= 4 and k >= 8: the same for the four elements)
+            const int addr = ((tid & 63) ^ d) << 2;                  // the eight exchanges of a step are issued before the first is waited for
+            u32 lo[4], hi[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                lo[r] = (u32)__builtin_amdgcn_ds_bpermute(addr, (int)(u32)v[r]);
+                hi[r] = (u32)__builtin_amdgcn_ds_bpermute(addr, (int)(u32)(v[r] >> 32));
             }
-            crossed = cross;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = keep(v[r], ((u64)hi[r] << 32) | lo[r], takemin);
+        }
+        if (k >= 4) {                                                // j = 2: (0, 2) and (1, 3)
+            const bool asc = ((e0 & k) == 0);                        // k = 4: bit 2 of the element = bit 0 of tid; in general bits >= 2
+            const u64 a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+            const bool s02 = (a0 > a2) == asc, s13 = (a1 > a3) == asc;
+            v[0] = s02 ? a2 : a0; v[2] = s02 ? a0 : a2; v[1] = s13 ? a3 : a1; v[3] = s13 ? a1 : a3;
+        }
+        {                                                            // j = 1: (0, 1) and (2, 3)
+            // k = 2: element e ascends iff bit 1 of e is clear: the pair (0, 1) ascends, (2, 3) descends; k >= 4: by the thread
+            const bool asc01 = k == 2 ? true : ((e0 & k) == 0), asc23 = k == 2 ? false : ((e0 & k) == 0);
+            const u64 a0 = v[0], a1 = v[1], a2 = v[2], a3 = v[3];
+            const bool s01 = (a0 > a1) == asc01, s23 = (a2 > a3) == asc23;
+            v[0] = s01 ? a1 : a0; v[1] = s01 ? a0 : a1; v[2] = s23 ? a3 : a2; v[3] = s23 ? a2 : a3;
         }
     }
-    __syncthreads();
-    for (int i = tid; i < SORT_CHUNK; i += 1024) g[i] = s[i];
+    *(uint4 *)&g[e0] = make_uint4((u32)v[0], (u32)(v[0] >> 32), (u32)v[1], (u32)(v[1] >> 32));
+    *(uint4 *)&g[e0 + 2] = make_uint4((u32)v[2], (u32)(v[2] >> 32), (u32)v[3], (u32)(v[3] >> 32));
 }
 
 __global__ __launch_bounds__(256) void k_nms_merge_rank(const float4 *__restrict__ boxes, const u64 *__restrict__ keys,
