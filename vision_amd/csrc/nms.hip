@@ -1429,6 +1429,9 @@ __global__ __launch_bounds__(1024) void k_nms_reduce_csr(const u64 *__restrict__
 //   k_nms_resolve_mc: the greedy keep list as a fixed point instead of a serial chain (below).
 #define XB_G 4096
 #define BAND_STAGE 256
+#ifndef BAND_ROWS
+#define BAND_ROWS 8      // rows of a tile per pass of k_nms_band's row loop
+#endif
 __device__ __forceinline__ int xb_bucket(float x, float xmin, float scale)
 {
     return (int)fminf(fmaxf((x - xmin) * scale, 0.0f), (float)(XB_G - 1));      // monotone in x; a NaN product (inf * 0) -> 0
@@ -1764,9 +1767,9 @@ __global__ __launch_bounds__(256, 4) void k_nms_band(const float4 *__restrict__ 
         // row slots whose band reaches this column tile (the tile's own diagonal tile: all of them)
         const int R = (j == t) ? 64 : __builtin_popcountll(__ballot(myjrow >= j));
 #pragma unroll 1
-        for (int r0 = 0; r0 < R; r0 += 8) {
+        for (int r0 = 0; r0 < R; r0 += BAND_ROWS) {
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < BAND_ROWS; ++u) {
                 const int r = r0 + u;                              // (slots past R in the last eight: tested too, harmless)
                 const float4 p = rbox[r];
                 const float ix = vmax(vmin(p.z, cx2) - vmax(p.x, cx1), 0.0f);
@@ -1789,7 +1792,7 @@ __global__ __launch_bounds__(256, 4) void k_nms_band(const float4 *__restrict__ 
         if (ambany) {                                             // rare: a quotient within one ulp of thr somewhere
             u64 w2 = 0;
 #pragma unroll 2
-            for (int r = 0; r < ((R + 7) & ~7); ++r) {
+            for (int r = 0; r < ((R + BAND_ROWS - 1) & ~(BAND_ROWS - 1)); ++r) {
                 const float4 p = rbox[r];
                 const float ix = fmaxf(fminf(p.z, cx2) - fmaxf(p.x, cx1), 0.0f);
                 const float iy = fmaxf(fminf(p.w, cy2) - fmaxf(p.y, cy1), 0.0f);
