@@ -1071,6 +1071,25 @@ def test_kmeans_vs_oracle(va, oracle, n, k):
     assert np.array_equal(km.predict(wh), labels)
 
 
+def test_kmeans_labels_are_copied_on_first_access(va, oracle):
+    """fit() leaves the labels on the device (uint8, `labels_device_`); `labels_` is sklearn's int32 ndarray, made on first
+    access and cached; a second fit gives the object new labels; before any fit both are None."""
+    from vision_amd import cluster
+    km = cluster.kmean(n_clusters=5, random_state=42)
+    assert km.labels_ is None and km.labels_device_ is None
+    wh = wl.anchor_wh(4, 30000)
+    km.fit(wh, fixed_iters=4)
+    assert km._labels_host is None and km.labels_device_.dtype == torch.uint8 and km.labels_device_.is_cuda
+    _, labels, _, _ = oracle.kmeans_fit(wh, 5, 42, fixed_iters=4)
+    got = km.labels_
+    assert got.dtype == np.int32 and np.array_equal(got, labels) and km.labels_ is got
+    assert np.array_equal(km.labels_device_.cpu().numpy().astype(np.int32), labels)
+    wh2 = wl.anchor_wh(5, 20000)
+    km.fit(wh2, fixed_iters=3)
+    _, labels2, _, _ = oracle.kmeans_fit(wh2, 5, 42, fixed_iters=3)
+    assert np.array_equal(km.labels_, labels2) and np.array_equal(km.fit_predict(wh, fixed_iters=4), labels)
+
+
 @pytest.mark.parametrize("iters", [1, 2, 7])
 def test_kmeans_fixed_iterations_vs_oracle(va, oracle, iters):
     """the device-side loop stopped after a fixed number of iterations (the bench's mode): centroids, labels and the
