@@ -393,11 +393,12 @@ def extra_kmeans(d, n_total=10_000_000, iters=30):
     shard = torch.from_numpy(wh_all[lo:hi]).to(d.dev)
     loops = None
     if d.world > 1 and not d.rehearse:
-        # every way to issue the sharded loop, most conservative first (launch + RCCL all-reduce per iteration from Python, the
-        # library's own C-side loop, then the two with the chunk captured in a HIP graph): the watchdog in main() publishes what
-        # has finished should a later one hang on this node
+        # every way to issue the sharded loop, most conservative first (launch + torch.distributed all-reduce per iteration from
+        # Python, the same captured with torch.cuda.graph, then the library's own communicator and C-side loop -- never run on
+        # more than one rank before an 8-GPU node sees it -- eager and captured): the watchdog in main() publishes what has
+        # finished should a later one hang on this node
         loops = {}
-        for name, comm, graph in (("torch_eager", "torch", "0"), ("so_eager", "so", "0"), ("torch_graph", "torch", "1"), ("so_graph", "so", "1")):
+        for name, comm, graph in (("torch_eager", "torch", "0"), ("torch_graph", "torch", "1"), ("so_eager", "so", "0"), ("so_graph", "so", "1")):
             os.environ["DG_KMEANS_GRAPH"] = graph
             try:                                   # a way that fails alike on every rank (no librccl.so, say) must not cost the others
                 ke = cluster.kmean(5, 42, comm=comm)
@@ -645,7 +646,7 @@ def main():
     torch.cuda.empty_cache()
     extra = {"phases_ms_rank0": phases, "grad_out_aliases_out": gout_alias, "config3_uint16_argmax": a16}
     line["roofline"] = roofline
-    dog = start_watchdog(d, line, extra, int(os.environ.get("DG_BENCH_EXTRAS_TIMEOUT", "420")))
+    dog = start_watchdog(d, line, extra, int(os.environ.get("DG_BENCH_EXTRAS_TIMEOUT", "240")))
 
     def side(name, fn):
         # a side configuration that fails is reported as such; it must not cost the primary line
