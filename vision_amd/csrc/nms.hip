@@ -2125,6 +2125,64 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_mc(NmsHdr *__restrict__ hd
 #define MC_BAIL (MC_SLOT + 1)       // 1: a workgroup ran out of rounds, 2: one stopped seeing progress
 #define MC_PASSES (MC_SLOT + 2)     // most list passes any workgroup made
 #define MC_IDLE_LIMIT (1 << 17)
+#define MC_LDS_LIST 8192       // entries of a pair list that k_nms_resolve_async keeps in LDS (32 KB)
+// One pass of a thread over its part of a pair list (k_nms_resolve_async): the 16-byte chunks tid, tid + 1024, ... of `lsrc`,
+// NCH of them in flight; survivors go back to the same chunks of `ldst` in order (in place: the write index never passes the
+// read index).  Sparse lists leave a thread one or two entries after the first passes, and the 32-entry batch -- 32 LDS
+// look-ups and as many skip tests whatever the count -- was most of a pass (stamps: 2.4 us of 4.6); a wave whose threads all
+// hold at most eight entries takes the 8-entry batch.
+template <int NCH>
+__device__ __forceinline__ int fp_list_pass(const u32 *lsrc, u32 *ldst, int mycnt, int tid, NmsFpShared &S, u32 own0)
+{
+    constexpr int NE = NCH * 4 > 16 ? 16 : NCH * 4;               // entries whose look-ups and returning atomics are in flight together
+    int out = 0;
+    const int nch = (mycnt + 3) >> 2;
+    for (int c0 = 0; c0 < nch; c0 += NCH) {
+        uint4 v[NCH];
+#pragma unroll
+        for (int u = 0; u < NCH; ++u)
+            v[u] = (c0 + u < nch) ? *(const uint4 *)(lsrc + 4 * (tid + 1024 * (c0 + u))) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int hh = 0; hh < NCH * 4 / NE; ++hh) {
+            u32 key[NE];
+            uint2 kr[NE];
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                const uint4 vv = v[hh * (NE / 4) + (i >> 2)];
+                key[i] = (i & 3) == 0 ? vv.x : ((i & 3) == 1 ? vv.y : ((i & 3) == 2 ? vv.z : vv.w));
+                kr[i] = *(const uint2 *)&S.KR[2 * (key[i] >> 21)];
+            }
+            u32 old[NE];                                         // the returning atomics of all of them issued before the first is waited for
+            u32 applied = 0;
+#pragma unroll
+            for (int i = 0; i < NE; ++i) {
+                old[i] = 0u;
+                if ((c0 + hh * (NE / 4)) * 4 + i >= mycnt) continue;
+                const u32 src = key[i] >> 16, dst = (key[i] & 0xffffu) - own0;
+                const u32 sb = 1u << (src & 31), db = 1u << (dst & 31);
+                if (kr[i].x & sb) {
+                    old[i] = atomicOr(&S.oR[dst >> 5], db);
+                    applied |= 1u << i;
+                } else if (!(kr[i].y & sb)) {
+                    atomicOr(&S.oBk[dst >> 5], db);
+                    ldst[((out >> 2) << 12) + (out & 3)] = key[i];
+                    ++out;
+                }
+            }
+            if (applied) {
+#pragma unroll
+                for (int i = 0; i < NE; ++i) {
+                    if (!((applied >> i) & 1u)) continue;
+                    const u32 dst = (key[i] & 0xffffu) - own0, db = 1u << (dst & 31);
+                    if (old[i] & db) atomicOr(&S.oR2[dst >> 5], db);
+                    else S.single[dst] = (unsigned short)(key[i] >> 16);
+                }
+            }
+        }
+    }
+    return out;
+}
+
 __global__ __launch_bounds__(1024) void k_nms_resolve_async(NmsHdr *__restrict__ hdr, const int32_t *__restrict__ counts, int64_t nmax,
                                                             int64_t Np, int64_t W, int64_t lcap, int lsh, int64_t ecap,
                                                             const int32_t *__restrict__ lcnt, const int32_t *__restrict__ order,
@@ -2132,6 +2190,7 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_async(NmsHdr *__restrict__
                                                             int64_t *__restrict__ keep, int32_t *__restrict__ keep_count)
 {
     __shared__ NmsFpShared S;
+    __shared__ __attribute__((aligned(16))) u32 s_list[MC_LDS_LIST];   // a list of at most this many entries lives here, not in memory
     const int img = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     NmsHdr *h = hdr + img;
     lcnt += img * 64 * LC_STRIDE;
@@ -2151,6 +2210,7 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_async(NmsHdr *__restrict__
     u32 *wmine = wlist + 4 * tid;
     const int E = lcnt[g * LC_STRIDE];                           // <= lcap (mode would be 1 otherwise)
     const int own0 = g << lsh, ow0 = own0 >> 5, nown = (1 << lsh) >> 5;
+    const bool inlds = E <= MC_LDS_LIST;                         // (uniform) no store to memory, and so no wait for one, in a pass
     if (tid < 32) { S.oK[tid] = 0u; S.oR[tid] = 0u; S.oR2[tid] = 0u; S.oBk[tid] = 0u; }
     __syncthreads();
     // round 0: boxes nothing suppresses are kept
@@ -2160,6 +2220,7 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_async(NmsHdr *__restrict__
         for (int u = 0; u < 8; ++u) {
             const int64_t c = c0 + u * 1024 + tid;
             v[u] = (c * 4 < E) ? *(const uint4 *)(list + 4 * c) : make_uint4(0, 0, 0, 0);
+            if (inlds && c * 4 < E) *(uint4 *)(s_list + 4 * c) = v[u];
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
@@ -2204,51 +2265,11 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_async(NmsHdr *__restrict__
             continue;
         }
         first = false; idle = 0;
-        int out = 0;
-        const int nch = (mycnt + 3) >> 2;
-        for (int c0 = 0; c0 < nch; c0 += 8) {
-            uint4 v[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                v[u] = (c0 + u < nch) ? *(const uint4 *)(src_list + 4 * (tid + 1024 * (c0 + u))) : make_uint4(0, 0, 0, 0);
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                u32 key[16];
-                uint2 kr[16];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    const uint4 vv = v[hh * 4 + (i >> 2)];
-                    key[i] = (i & 3) == 0 ? vv.x : ((i & 3) == 1 ? vv.y : ((i & 3) == 2 ? vv.z : vv.w));
-                    kr[i] = *(const uint2 *)&S.KR[2 * (key[i] >> 21)];
-                }
-                u32 old[16];                                     // the returning atomics of all 16 issued before the first is waited for
-                u32 applied = 0;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    old[i] = 0u;
-                    if ((c0 + hh * 4) * 4 + i >= mycnt) continue;
-                    const u32 src = key[i] >> 16, dst = (key[i] & 0xffffu) - (u32)own0;
-                    const u32 sb = 1u << (src & 31), db = 1u << (dst & 31);
-                    if (kr[i].x & sb) {
-                        old[i] = atomicOr(&S.oR[dst >> 5], db);
-                        applied |= 1u << i;
-                    } else if (!(kr[i].y & sb)) {
-                        atomicOr(&S.oBk[dst >> 5], db);
-                        wmine[((out >> 2) << 12) + (out & 3)] = key[i];
-                        ++out;
-                    }
-                }
-                if (applied) {
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        if (!((applied >> i) & 1u)) continue;
-                        const u32 dst = (key[i] & 0xffffu) - (u32)own0, db = 1u << (dst & 31);
-                        if (old[i] & db) atomicOr(&S.oR2[dst >> 5], db);
-                        else S.single[dst] = (unsigned short)(key[i] >> 16);
-                    }
-                }
-            }
-        }
+        // (a wave's threads hold about equally many entries: which batch a wave takes is decided per wave)
+        const bool few = __ballot(mycnt > 8) == 0ull;
+        int out;
+        if (inlds) out = few ? fp_list_pass<2>(s_list, s_list + 4 * tid, mycnt, tid, S, (u32)own0) : fp_list_pass<8>(s_list, s_list + 4 * tid, mycnt, tid, S, (u32)own0);
+        else out = few ? fp_list_pass<2>(src_list, wmine, mycnt, tid, S, (u32)own0) : fp_list_pass<8>(src_list, wmine, mycnt, tid, S, (u32)own0);
         mycnt = out;
         src_list = wlist;
         __syncthreads();
@@ -2275,28 +2296,31 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_async(NmsHdr *__restrict__
 #pragma unroll
         for (int d = 32; d > 0; d >>= 1) { kc += __shfl_xor(kc, d, 64); km = max(km, __shfl_xor(km, d, 64)); }
         if (lane == 0) {
-            mc_st(&mcs[MC_KCNT + g], (u32)kc); mc_st(&mcs[MC_KMAX + g], (u32)km); mc_st(&mcs[MC_SNGL + g], (u32)S.sngl);
-            if (bail || stuck) atomicMax(&mcs[MC_BAIL], stuck ? 2u : 1u);
+            // kept count (<= 1024), highest kept rank + 1 and highest sole suppressor + 1 (<= 65536 each) in ONE 64-bit word per
+            // workgroup (over the MC_KCNT / MC_KMAX areas): one trip for whoever reads them, not three
+            __hip_atomic_store((unsigned long long *)&mcs[MC_KCNT + 2 * g],
+                               (unsigned long long)kc | ((unsigned long long)km << 16) | ((unsigned long long)S.sngl << 40),
+                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (bail || stuck) atomicMax(&mcs[MC_BAIL], stuck ? 2u : 1u);   // (what the others poll while they still pass)
             atomicMax(&mcs[MC_PASSES], (u32)passes);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // what this thread published has arrived
     __syncthreads();
     if (tid == 0) {
-        atomicAdd(&mcs[MC_ARR], 1u);
-        u32 spins = 0;
+        // arrivals in the low byte, those that ran out of rounds and those that were stuck in the next two: the word the wait
+        // spins on says everything
+        atomicAdd(&mcs[MC_ARR], 1u | (bail ? 1u << 8 : 0u) | (stuck ? 1u << 16 : 0u));
+        u32 spins = 0, v;
         int ok = 1;
-        while (mc_ld(&mcs[MC_ARR]) < (u32)MC_G) {
+        while (((v = mc_ld(&mcs[MC_ARR])) & 0xffu) < (u32)MC_G) {
             __builtin_amdgcn_s_sleep(1);
             if (++spins > MC_SPIN_LIMIT) { ok = 0; break; }
         }
-        const u32 b = mc_ld(&mcs[MC_BAIL]);
-        S.ok = (ok && b != 2u) ? 1 : 0;
-        S.live = (unsigned long long)b;
-        S.cnt[3] = (int)mc_ld(&mcs[MC_PASSES]);
+        S.ok = (ok && (v >> 16) == 0u) ? 1 : 0;
+        S.live = (unsigned long long)((v >> 8) & 0xffu);
     }
     __syncthreads();
-    const int rounds = S.cnt[3];
     if (!S.ok) {                                                  // a workgroup never arrived, or one stopped seeing progress
         if (g == 0 && tid == 0) {
             if (Etot <= ecap) { h->fpdone = 0; }                  // the serial chain does this image
@@ -2306,13 +2330,14 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_async(NmsHdr *__restrict__
         return;
     }
     if (S.live != 0ull) {                                         // uniform over the grid: k_nms_reduce_csr<SEG> does this image from scratch
-        if (g == 0 && tid == 0) { h->fpdone = 0; h->rounds = rounds; h->npairs = Etot; }
+        if (g == 0 && tid == 0) { h->fpdone = 0; h->rounds = (int)mc_ld(&mcs[MC_PASSES]); h->npairs = Etot; }
         return;
     }
     __syncthreads();
     // ---- the kept set is final and every workgroup's counts are out: keep list in rank order, each workgroup its targets
     if (wave == 0) {
-        int kc = (int)mc_ld(&mcs[MC_KCNT + lane]), km = (int)mc_ld(&mcs[MC_KMAX + lane]), sg = (int)mc_ld(&mcs[MC_SNGL + lane]);
+        const unsigned long long pk = __hip_atomic_load((const unsigned long long *)&mcs[MC_KCNT + 2 * lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int kc = (int)(pk & 0xffffull), km = (int)((pk >> 16) & 0xffffffull), sg = (int)(pk >> 40);
         int incl = kc;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
@@ -2336,7 +2361,7 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_async(NmsHdr *__restrict__
         if (((kw >> (tid & 31)) & 1u) && !(drop && t == km))
             keep[S.off[tid >> 5] + __builtin_popcount(kw & ((1u << (tid & 31)) - 1u))] = (int64_t)order[t];
     }
-    if (g == 0 && tid == 0) { keep_count[img] = total - drop; h->fpdone = 1; h->rounds = rounds; h->npairs = Etot; }
+    if (g == 0 && tid == 0) { keep_count[img] = total - drop; h->fpdone = 1; h->rounds = (int)mc_ld(&mcs[MC_PASSES]); h->npairs = Etot; }
 }
 
 // ---------------------------------------------------------------- host
