@@ -14,6 +14,6 @@ for dense, thr in ((False, 0.5), (True, 0.5)):
     abi.load().dg_debug_nms_stamps(out)
     a = np.array(out[:], dtype=np.float64).reshape(64, 8)
     print("dense", dense, "thr", thr, "(cycles of the 100 MHz/shader counter per workgroup; cols: publish+count, snapshot, idle polls, list pass, tail/total, loop total, idle count, passes)")
-    for g in (0, 1, 8, 16, 32, 48, 62, 63):
+    for g in range(64):
         print("  wg %2d" % g, " ".join("%9.0f" % v for v in a[g]))
     print("  mean ", " ".join("%9.0f" % v for v in a.mean(0)))

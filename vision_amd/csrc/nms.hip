@@ -2245,18 +2245,25 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_async(NmsHdr *__restrict__
         if (passes >= max_rounds && Etot <= ecap) { bail = true; break; }
         // what the others have published by now; the own words as they are here
         int ch = first ? 1 : 0;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int w = tid + 1024 * q;
-            if (w < 2 * (int)W) {
-                const bool own = w >= ow0 && w < ow0 + nown;
-                const u32 k = own ? S.oK[w - ow0] : mc_ld(&mcs[MC_K + w]);
-                const u32 r = own ? S.oR[w - ow0] : mc_ld(&mcs[MC_R + w]);
-                ch |= (k != S.KR[2 * w]) | (r != S.KR[2 * w + 1]);
-                S.KR[2 * w] = k; S.KR[2 * w + 1] = r;
-            }
+        {
+            // the thread's four words and the bail flag: five agent-scope loads issued together, ONE wait (the compiler waits
+            // for every atomic load in turn, and with the own-word branches between them that was four trips a pass)
+            const int w0 = tid, w1 = tid + 1024;
+            const bool v1 = w1 < 2 * (int)W;                       // (w0 < 2 W always: W > 64)
+            const u32 *pk0 = &mcs[MC_K + w0], *pr0 = &mcs[MC_R + w0], *pk1 = &mcs[MC_K + (v1 ? w1 : w0)], *pr1 = &mcs[MC_R + (v1 ? w1 : w0)];
+            const u32 *pb = &mcs[MC_BAIL];
+            u32 k0, r0, k1, r1, bl;
+            asm volatile("global_load_dword %0, %5, off sc1\n\tglobal_load_dword %1, %6, off sc1\n\tglobal_load_dword %2, %7, off sc1\n\t"
+                         "global_load_dword %3, %8, off sc1\n\tglobal_load_dword %4, %9, off sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(k0), "=&v"(r0), "=&v"(k1), "=&v"(r1), "=&v"(bl)
+                         : "v"(pk0), "v"(pr0), "v"(pk1), "v"(pr1), "v"(pb) : "memory");
+            if (w0 >= ow0 && w0 < ow0 + nown) { k0 = S.oK[w0 - ow0]; r0 = S.oR[w0 - ow0]; }      // the own words as they are here
+            if (w1 >= ow0 && w1 < ow0 + nown) { k1 = S.oK[w1 - ow0]; r1 = S.oR[w1 - ow0]; }
+            ch |= (k0 != S.KR[2 * w0]) | (r0 != S.KR[2 * w0 + 1]);
+            S.KR[2 * w0] = k0; S.KR[2 * w0 + 1] = r0;
+            if (v1) { ch |= (k1 != S.KR[2 * w1]) | (r1 != S.KR[2 * w1 + 1]); S.KR[2 * w1] = k1; S.KR[2 * w1 + 1] = r1; }
+            if (tid == 0) S.sngl = (int)bl;                        // somebody has given up: so does everybody
         }
-        if (tid == 0) S.sngl = (int)mc_ld(&mcs[MC_BAIL]);           // somebody has given up: so does everybody
         const int changed = __syncthreads_or(ch);
         if (S.sngl) { bail = true; break; }
         if (changed == 0) {                                        // nothing new: no pass
