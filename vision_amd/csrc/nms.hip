@@ -2183,6 +2183,21 @@ __device__ __forceinline__ int fp_list_pass(const u32 *lsrc, u32 *ldst, int mycn
     return out;
 }
 
+// Diagnostic build (-DDG_NMS_STAMPS, tools/dbg_nms_stamps.py; never the product): where a workgroup of k_nms_resolve_async
+// spends its cycles -- per phase of a pass, then per phase of the ending -- for image 0 of the last launch.
+#ifdef DG_NMS_STAMPS
+__device__ unsigned long long nms_dbg[64][8];
+extern "C" int dg_debug_nms_stamps(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(nms_dbg), sizeof(nms_dbg)) == hipSuccess ? 0 : -4; }
+#define FPSTAMP_DECL unsigned long long acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter(), tstart = tprev
+#define FPSTAMP(k) do { if (tid == 0) { const unsigned long long now = __builtin_readcyclecounter(); acc[k] += now - tprev; tprev = now; } } while (0)
+#define FPSTAMP_LOOP_END do { if (tid == 0) { acc[7] = passes; acc[5] = __builtin_readcyclecounter() - tstart; acc[6] = acc[0]; acc[0] = acc[1] = acc[2] = acc[3] = 0; tprev = __builtin_readcyclecounter(); } } while (0)
+#define FPSTAMP_OUT do { if (tid == 0 && img == 0) { acc[4] = __builtin_readcyclecounter() - tstart; for (int k = 0; k < 8; ++k) nms_dbg[g][k] = acc[k]; } } while (0)
+#else
+#define FPSTAMP_DECL do { } while (0)
+#define FPSTAMP(k) do { } while (0)
+#define FPSTAMP_LOOP_END do { } while (0)
+#define FPSTAMP_OUT do { } while (0)
+#endif
 __global__ __launch_bounds__(1024) void k_nms_resolve_async(NmsHdr *__restrict__ hdr, const int32_t *__restrict__ counts, int64_t nmax,
                                                             int64_t Np, int64_t W, int64_t lcap, int lsh, int64_t ecap,
                                                             const int32_t *__restrict__ lcnt, const int32_t *__restrict__ order,
@@ -2236,12 +2251,15 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_async(NmsHdr *__restrict__
     const u32 *src_list = list;
     int mycnt = 0;
     for (int64_t c = tid; c * 4 < E; c += 1024) mycnt += (E - c * 4 >= 4) ? 4 : (int)(E - c * 4);
+    FPSTAMP_DECL;
     int passes = 0, idle = 0;
     bool bail = false, stuck = false, first = true;
     for (;;) {
         __syncthreads();                                           // the own words of the last pass are complete
         if (tid < nown) { mc_st(&mcs[MC_K + ow0 + tid], S.oK[tid]); mc_st(&mcs[MC_R + ow0 + tid], S.oR[tid]); }
-        if (__syncthreads_or(mycnt != 0) == 0) break;              // the list is empty: every owned target is decided
+        const int anyleft = __syncthreads_or(mycnt != 0);
+        FPSTAMP(0);
+        if (anyleft == 0) break;              // the list is empty: every owned target is decided
         if (passes >= max_rounds && Etot <= ecap) { bail = true; break; }
         // what the others have published by now; the own words as they are here
         int ch = first ? 1 : 0;
@@ -2265,10 +2283,12 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_async(NmsHdr *__restrict__
             if (tid == 0) S.sngl = (int)bl;                        // somebody has given up: so does everybody
         }
         const int changed = __syncthreads_or(ch);
+        FPSTAMP(1);
         if (S.sngl) { bail = true; break; }
         if (changed == 0) {                                        // nothing new: no pass
             if (++idle > MC_IDLE_LIMIT) { stuck = true; break; }
             __builtin_amdgcn_s_sleep(16);
+            FPSTAMP(2);
             continue;
         }
         first = false; idle = 0;
@@ -2280,12 +2300,14 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_async(NmsHdr *__restrict__
         mycnt = out;
         src_list = wlist;
         __syncthreads();
+        FPSTAMP(3);
         if (tid < 32) {                                            // what nothing blocks is kept
             S.oK[tid] |= (tid < nown ? nms_valid32(ow0 + tid, n) : 0u) & ~(S.oK[tid] | S.oR[tid] | S.oBk[tid]);
             S.oBk[tid] = 0u;
         }
         ++passes;
     }
+    FPSTAMP_LOOP_END;
     // ---- finished (the final words went out at the top of the last turn), out of rounds, or stuck: tell the others, wait for all
     if (tid == 0) S.sngl = 0;
     __syncthreads();
@@ -2297,6 +2319,7 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_async(NmsHdr *__restrict__
         if (lane == 0 && v) atomicMax(&S.sngl, v);
     }
     __syncthreads();
+    FPSTAMP(0);
     if (wave == 1) {
         const u32 kw = lane < nown ? S.oK[lane] : 0u;
         int kc = __builtin_popcount(kw), km = kw ? (ow0 + lane) * 32 + 32 - __builtin_clz(kw) : 0;
@@ -2314,6 +2337,7 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_async(NmsHdr *__restrict__
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // what this thread published has arrived
     __syncthreads();
+    FPSTAMP(1);
     if (tid == 0) {
         // arrivals in the low byte, those that ran out of rounds and those that were stuck in the next two: the word the wait
         // spins on says everything
@@ -2328,6 +2352,7 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_async(NmsHdr *__restrict__
         S.live = (unsigned long long)((v >> 8) & 0xffu);
     }
     __syncthreads();
+    FPSTAMP(2);
     if (!S.ok) {                                                  // a workgroup never arrived, or one stopped seeing progress
         if (g == 0 && tid == 0) {
             if (Etot <= ecap) { h->fpdone = 0; }                  // the serial chain does this image
@@ -2360,6 +2385,7 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_async(NmsHdr *__restrict__
         if (lane == 0) { S.cnt[0] = total; S.cnt[1] = km; S.cnt[2] = sg; }
     }
     __syncthreads();
+    FPSTAMP(3);
     const int total = S.cnt[0], km = S.cnt[1] - 1;                 // km: the last kept box (-1: none)
     const int drop = (quirk && total > 0 && S.cnt[2] - 1 != km) ? 1 : 0;
     if (tid < (1 << lsh)) {
@@ -2369,6 +2395,7 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_async(NmsHdr *__restrict__
             keep[S.off[tid >> 5] + __builtin_popcount(kw & ((1u << (tid & 31)) - 1u))] = (int64_t)order[t];
     }
     if (g == 0 && tid == 0) { keep_count[img] = total - drop; h->fpdone = 1; h->rounds = (int)mc_ld(&mcs[MC_PASSES]); h->npairs = Etot; }
+    FPSTAMP_OUT;
 }
 
 // ---------------------------------------------------------------- host
