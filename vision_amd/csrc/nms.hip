@@ -1709,6 +1709,7 @@ __global__ __launch_bounds__(256, 4) void k_nms_band(const float4 *__restrict__ 
         // its rank and its place): column tile j then needs the first R_j row slots only, those whose band reaches it -- a
         // tile's bands differ by the boxes' widths, and running all 64 rows to the end of the widest cost 1.8 x the pairs.
         s_jtmp[tid] = jend;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // (one wave wrote them, the same wave reads them all)
         int slot = 0;
 #pragma unroll 8
         for (int k = 0; k < 64; ++k) { const int jk = s_jtmp[k]; slot += (jk > jend || (jk == jend && k < tid)) ? 1 : 0; }
