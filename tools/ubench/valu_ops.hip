@@ -58,6 +58,20 @@ __global__ __launch_bounds__(256) void k(float *out, const float *in, int iters)
                 if (PAT == 23) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(b[i]) : "v"(v[i]), "v"(v[(i + 1) % NCH]));
                 if (PAT == 24) asm volatile("v_lshl_or_b32 %0, %0, 1, %1" : "+v"(c[i]) : "v"(r[i]));
                 if (PAT == 25) asm volatile("v_cmp_eq_u32 vcc, %0, %1" : : "v"(c[i]), "v"(r[i]) : "vcc");
+                if (PAT == 26) asm volatile("v_min_f64 %0, %0, %1" : "+v"(p[i]) : "v"(q[i]));
+                if (PAT == 27) asm volatile("v_max_f64 %0, %0, %1" : "+v"(p[i]) : "v"(q[i]));
+                if (PAT == 28) asm volatile("v_cmp_lt_u64 vcc, %0, %1" : : "v"(p[i]), "v"(q[i]) : "vcc");
+                if (PAT == 29) asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(p[i]) : "v"(q[i]));
+                if (PAT == 30) asm volatile("v_add_u32 %0, %0, %1" : "+v"(c[i]) : "v"(r[i]));
+                if (PAT == 31) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(c[i]) : "v"(r[i]));
+                if (PAT == 32) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(c[i]));
+                if (PAT == 33) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(b[i]) : "v"(v[i]));
+                if (PAT == 34) asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(b[i]) : "v"(v[i]));
+                if (PAT == 35) asm volatile("v_mad_u32_u24 %0, %0, %1, %1" : "+v"(c[i]) : "v"(r[i]));
+                if (PAT == 36) asm volatile("v_min_f32 %0, %0, %1" : "+v"(b[i]) : "v"(v[i]));
+                if (PAT == 37) asm volatile("v_rcp_f32 %0, %0" : "+v"(b[i]));
+                if (PAT == 38) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(p[i]) : "v"(b[i]));
+                if (PAT == 39) asm volatile("v_or_b32 %0, %0, %1" : "+v"(c[i]) : "v"(r[i]));
             }
         }
     }
@@ -83,7 +97,7 @@ template <int PAT> void run(const char *name, int nvalu, int wavesPerSimd, float
 int main()
 {
     float *out, *in; (void)hipMalloc(&out, 256 * 2048 * 4); (void)hipMalloc(&in, 4096 * 4); (void)hipMemset(in, 0, 4096 * 4);
-    for (int w = 2; w <= 8; w *= 2) {
+    for (int w = 2; w <= 4; w *= 2) {
         run<0>("v_max_f32", 1, w, out, in);
         run<1>("v_cmp_gt_f32 vcc", 1, w, out, in);
         run<12>("v_cmp_gt_f32_e64 sgpr", 1, w, out, in);
@@ -104,6 +118,20 @@ int main()
         run<22>("v_max_i32", 1, w, out, in);
         run<18>("v_and_b32", 1, w, out, in);
         run<24>("v_lshl_or_b32", 1, w, out, in);
+        run<36>("v_min_f32", 1, w, out, in);
+        run<33>("v_mul_f32", 1, w, out, in);
+        run<34>("v_fma_f32", 1, w, out, in);
+        run<37>("v_rcp_f32", 1, w, out, in);
+        run<30>("v_add_u32", 1, w, out, in);
+        run<31>("v_xor_b32", 1, w, out, in);
+        run<39>("v_or_b32", 1, w, out, in);
+        run<32>("v_lshlrev_b32", 1, w, out, in);
+        run<35>("v_mad_u32_u24", 1, w, out, in);
+        run<26>("v_min_f64", 1, w, out, in);
+        run<27>("v_max_f64", 1, w, out, in);
+        run<29>("v_fma_f64", 1, w, out, in);
+        run<38>("v_cvt_f64_f32", 1, w, out, in);
+        run<28>("v_cmp_lt_u64 vcc", 1, w, out, in);
         run<8>("cmp + cndmask + max (current scan)", 3, w, out, in);
         run<20>("cmp + max", 2, w, out, in);
         run<9>("cmpx + pk_mov + s_mov exec", 2, w, out, in);
