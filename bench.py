@@ -414,9 +414,39 @@ def extra_kmeans(d, n_total=10_000_000, iters=30):
         os.environ.pop("DG_KMEANS_GRAPH", None)
     km = cluster.kmean(5, 42, reduce_device="cpu" if d.rehearse else None)   # rehearsal: gloo reduces host tensors
     km.fit(shard, init_centers=init, fixed_iters=iters)     # warm-up (RCCL channels, graph capture); leaves the device state
-    sec = min(Dist.timed(d, lambda: km._run_iters(0, iters), 1, 0) for _ in range(5))   # the Lloyd iterations proper
-    # device time of one iteration on this rank's shard (HIP events around the same 30 iterations: no host sync in it)
-    ms = min(ev_time(lambda: km._run_iters(0, iters), 3, 1) for _ in range(3)) / iters
+    single = d.world == 1 and not d.rehearse
+    replay = None
+    if single:
+        # one device: the timed iterations are A FIT'S -- from the initial centroids, labels unset, boxes regrouped (the reset is
+        # not timed; the grouping's time is reported apart as prepare_device_ms).  The prepared iterations depend on the state
+        # (pieces move between "decided as a whole" and "walked" while the centroids move), so a replay from the state the fit
+        # left is a different, slightly lighter workload: reported beside it as `replay_from_fitted_state`.
+        be = km._backend
+        init_dev = torch.from_numpy(np.asarray(init, np.float32)).to(d.dev).reshape(be.cent.shape)
+
+        def reset():
+            be.cent.copy_(init_dev)
+            be.labels.fill_(255)
+            if getattr(be, "cells", None) is not None:
+                be.reprepare(fresh=True)                        # as fit() does: no labels yet
+
+        def fit_iters_wall():
+            reset()
+            return Dist.timed(d, lambda: km._run_iters(0, iters), 1, 0)
+
+        def fit_iters_dev():
+            reset()
+            return ev_time(lambda: km._run_iters(0, iters), 1, 0)
+
+        sec = min(fit_iters_wall() for _ in range(5))
+        ms = min(fit_iters_dev() for _ in range(3)) / iters
+        fitted_again = bool(np.array_equal(be.cent.cpu().numpy().reshape(-1), np.asarray(km.cluster_centers_).reshape(-1)))
+        replay = {"ms_per_iter": min(Dist.timed(d, lambda: km._run_iters(0, iters), 1, 0) for _ in range(5)) / iters * 1e3,
+                  "device_ms_per_iter": min(ev_time(lambda: km._run_iters(0, iters), 3, 1) for _ in range(3)) / iters}
+    else:
+        sec = min(Dist.timed(d, lambda: km._run_iters(0, iters), 1, 0) for _ in range(5))   # the Lloyd iterations proper (box loop: state-independent)
+        # device time of one iteration on this rank's shard (HIP events around the same 30 iterations: no host sync in it)
+        ms = min(ev_time(lambda: km._run_iters(0, iters), 3, 1) for _ in range(3)) / iters
     r = {"iters_per_s": iters / sec, "ms_per_iter": sec / iters * 1e3, "boxes_total": n_total, "ranks": d.world,
          "sharded_loop": km.graph_state if d.world > 1 else "single device: dg_kmeans_iou_run",
          "comm": km.comm_state if d.world > 1 else None,
@@ -437,6 +467,10 @@ def extra_kmeans(d, n_total=10_000_000, iters=30):
         # (k_kmeans_step every iteration, what the sharded fit still runs) beside it, with its HBM fraction at SURVEY's
         # 12 B/box and at the bytes the kernel really moves (8 B box + 1 B old label + 1 B new label = 10 B/box)
         r["path"] = "prepared (cells)" if getattr(km._backend, "cells", None) is not None else "box loop"
+        r["timed"] = ("the 30 iterations of a fit from the initial centroids (state reset and boxes regrouped before every timed run, "
+                      "untimed), best of 5; replay_from_fitted_state = the same 30 launches started from the state the fit left")
+        r["replay_from_fitted_state"] = replay
+        r["timed_fit_reaches_the_fit_centroids"] = fitted_again
         r["iter_hbm_frac_note"] = ("the prepared iterations do not read the boxes they decide piece-wise, so SURVEY's 12 B/box over "
                                    "their time is an equivalent rate, not memory traffic")
         try:
@@ -466,7 +500,9 @@ def extra_kmeans(d, n_total=10_000_000, iters=30):
             kp = cluster.kmean(5, 42); kp.fit(shard, init_centers=init, fixed_iters=iters)
             be = kp._backend
             if getattr(be, "cells", None) is not None and hasattr(be, "reprepare"):
-                r["prepare_device_ms"] = min(ev_time(be.reprepare, 3, 1) for _ in range(3))
+                be.labels.fill_(255)
+                r["prepare_device_ms"] = min(ev_time(lambda: be.reprepare(fresh=True), 3, 1) for _ in range(3))   # a fit's: no labels yet
+                r["prepare_device_ms_with_labels"] = min(ev_time(be.reprepare, 3, 1) for _ in range(3))            # re-grouping mid-fit
         except Exception as e:  # noqa: BLE001
             r["box_loop"] = {"error": f"{type(e).__name__}: {e}"}
         finally:

@@ -229,7 +229,9 @@ int dg_kmeans_labels_i32(const uint8_t *labels, int64_t n, int32_t *out, dg_stre
  * what dg_kmeans_iou_run gives (cent, labels, acc, history: bit for bit) but decides whole pieces at once wherever the
  * cell's bounds on the IoUs leave no doubt about the label, and walks only the other pieces box by box.  The workspace is
  * bound to the CONTENTS of wh and to the labels as they were at prepare time: prepare again when either changes behind the
- * library's back (labels written by dg_kmeans_iou_run_prepared itself are tracked).  ws 256-byte aligned. */
+ * library's back (labels written by dg_kmeans_iou_run_prepared itself are tracked).  labels == NULL says that no box has a
+ * label yet (what a fit starts from: every box then counts as changed by the first iteration, exactly as an array of 255s
+ * would make it) and saves moving n label bytes one by one.  ws 256-byte aligned. */
 size_t dg_kmeans_prepared_workspace_bytes(int64_t n, int64_t k);
 int dg_kmeans_prepare(const float *wh, int64_t n, int64_t k, const uint8_t *labels, void *ws, size_t ws_bytes, dg_stream_t s);
 int dg_kmeans_iou_run_prepared(const float *wh, int64_t n, float *cent, int64_t k, uint8_t *labels, int64_t *acc,

@@ -1138,6 +1138,16 @@ def test_kmeans_prepared_fit_vs_oracle(va, oracle, n, k, iters, monkeypatch):
         for _ in range(iters + 3):
             acc = oracle.kmeans_step(wh, ce, lab); hist.append(int(acc[3 * k])); ce = oracle.kmeans_update(acc, ce)
         assert list(c._backend.history_host(3)) == hist[iters:iters + 3]
+        # the changed counts from the very first iteration (the fit prepares without labels: every box counts as changed once)
+        assert list(a._backend.history_host(iters)) == hist[:iters]
+        # grouping again in mid-fit, this time with the labels the fit has reached, then continuing: the same three iterations
+        e = cluster.kmean(k, 42).fit(x, fixed_iters=iters)
+        e._backend.reprepare()
+        e._run_iters(0, 3)
+        torch.cuda.synchronize()
+        assert np.array_equal(e._backend.cent.cpu().numpy().view(np.uint32), cent2.view(np.uint32))
+        assert np.array_equal(e._backend.labels.cpu().numpy().astype(np.int32), labels2)
+        assert list(e._backend.history_host(3)) == hist[iters:iters + 3]
 
 
 def test_kmeans_sharded_equals_single(va, oracle):

@@ -1,6 +1,7 @@
 """Turn a rocprofv3 rocpd database (<out>_results.db) into small CSV summaries.
 usage: python tools/rocpd_summary.py stats <db> > kernel_stats.csv      # per (kernel, grid) durations
        python tools/rocpd_summary.py pmc <db> [kernel-substring]         # per (kernel, grid, counter) means
+       python tools/rocpd_summary.py timeline <db> [last-n]              # the last n launches in order: start, duration, gap
 Launches of one kernel at different grid sizes are kept apart so that the bench's full-size launches
 are not averaged with the small side configurations that run in the same process."""
 import math
@@ -25,6 +26,14 @@ def main():
         print("kernel,grid_threads,workgroup,duration_decade_us,calls,total_us,avg_us,min_us,max_us,percent")
         for (n, g, wg, dec), v in sorted(groups.items(), key=lambda kv: -sum(kv[1])):
             print(f"\"{n}\",{g},{wg},1e{dec},{len(v)},{sum(v):.1f},{sum(v)/len(v):.2f},{min(v):.2f},{max(v):.2f},{100*sum(v)/tot:.2f}")
+    elif mode == "timeline":
+        last = int(sys.argv[3]) if len(sys.argv) > 3 else 100
+        rows = con.execute("select name, grid_x*grid_y*grid_z, workgroup_x*workgroup_y*workgroup_z, start, end from kernels order by start").fetchall()[-last:]
+        print("start_us,duration_us,gap_before_us,grid_threads,workgroup,kernel")
+        t0, prev = rows[0][3], None
+        for n, g, wg, st, en in rows:
+            print(f"{(st-t0)/1e3:.1f},{(en-st)/1e3:.1f},{((st-prev)/1e3 if prev is not None else 0):.1f},{g},{wg},\"{short(n)}\"")
+            prev = en
     else:
         sub = sys.argv[3] if len(sys.argv) > 3 else ""
         rows = con.execute("select kernel_name, grid_size, counter_name, count(*), avg(value), avg(duration) from counters_collection "

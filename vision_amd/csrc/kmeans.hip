@@ -707,6 +707,9 @@ extern "C" int dg_kmeans_labels_i32(const uint8_t *labels, int64_t n, int32_t *o
 #define KC_PIECE 256
 #define KC_WG_PIECES 64
 #define KC_MAGIC 0x4b43656c6c733033ull
+#define KC_PER_BOX 255                                            // plab: the piece's boxes carry their own labels (slab)
+#define KC_UNSET 254                                              // plab: no box of the piece has a label yet (a label no centroid has: every comparison counts as changed)
+#define KC_Q_COUNT (1 << 24)                                      // walk-queue entry: the piece is decided, count its changed labels only
 struct KcHdr {
     unsigned long long magic;
     const void *wh;
@@ -782,43 +785,63 @@ __global__ __launch_bounds__(256) void k_kc_colscan(int *__restrict__ counts, in
     for (int g = 0; g < KC_G; ++g) { const int v = counts[(size_t)g * KC_NC + c]; counts[(size_t)g * KC_NC + c] = run; run += v; }
     tot[c] = run;
 }
-// one workgroup: where every cell starts in the sorted order, and its first piece
+// one workgroup: where every cell starts in the sorted order, and its first piece.  Everything goes through LDS so that memory
+// sees coalesced accesses only: a thread reading its 26 consecutive cells from memory, three times over, took 52 us of
+// dependent trips; the same thread writing its 2 x 26 results straight to memory 30 us (every wave store touched 64 lines)
 __global__ __launch_bounds__(1024) void k_kc_scan(const int *__restrict__ tot, int *__restrict__ cell_start, int *__restrict__ piece_first,
                                                   KcHdr *__restrict__ hdr, const void *wh, long long n, int k)
 {
-    __shared__ int s_a[1024], s_b[1024];
-    const int tid = threadIdx.x;
+    extern __shared__ int kc_h[];                                // KC_NC totals, then one exclusive prefix after the other
+    __shared__ unsigned long long s_w[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int PER = (KC_NC + 1023) / 1024;
-    int a = 0, b = 0;
-    for (int j = 0; j < PER; ++j) { const int c = tid * PER + j; if (c < KC_NC) { a += tot[c]; b += (tot[c] + KC_PIECE - 1) / KC_PIECE; } }
-    s_a[tid] = a; s_b[tid] = b;
+    for (int c = tid; c < KC_NC; c += 1024) kc_h[c] = tot[c];
     __syncthreads();
-    for (int o = 1; o < 1024; o <<= 1) {
-        const int va = tid >= o ? s_a[tid - o] : 0, vb = tid >= o ? s_b[tid - o] : 0;
-        __syncthreads();
-        s_a[tid] += va; s_b[tid] += vb;
-        __syncthreads();
-    }
-    int ra = s_a[tid] - a, rb = s_b[tid] - b;
+    int t[PER];
+    unsigned long long ab = 0;                                   // boxes in the low word, pieces in the high one: one scan for both
+#pragma unroll
     for (int j = 0; j < PER; ++j) {
         const int c = tid * PER + j;
-        if (c < KC_NC) { cell_start[c] = ra; piece_first[c] = rb; ra += tot[c]; rb += (tot[c] + KC_PIECE - 1) / KC_PIECE; }
+        t[j] = c < KC_NC ? kc_h[c] : 0;
+        ab += (unsigned long long)(unsigned)t[j] | ((unsigned long long)(unsigned)((t[j] + KC_PIECE - 1) / KC_PIECE) << 32);
     }
+    unsigned long long inc = ab;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned long long v = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += v;
+    }
+    if (lane == 63) s_w[wave] = inc;
+    __syncthreads();
+    unsigned long long base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) { if (w < wave) base += s_w[w]; total += s_w[w]; }
+    const unsigned long long ex = base + inc - ab;
+    int ra = (int)(unsigned)ex, rb = (int)(unsigned)(ex >> 32);
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { const int c = tid * PER + j; if (c < KC_NC) kc_h[c] = ra; ra += t[j]; }
+    __syncthreads();
+    for (int c = tid; c < KC_NC; c += 1024) cell_start[c] = kc_h[c];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { const int c = tid * PER + j; if (c < KC_NC) kc_h[c] = rb; rb += (t[j] + KC_PIECE - 1) / KC_PIECE; }
+    __syncthreads();
+    for (int c = tid; c < KC_NC; c += 1024) piece_first[c] = kc_h[c];
     if (tid == 1023) {
-        cell_start[KC_NC] = s_a[1023]; piece_first[KC_NC] = s_b[1023];
-        hdr->magic = KC_MAGIC; hdr->wh = wh; hdr->n = n; hdr->k = k; hdr->npieces = s_b[1023];
+        cell_start[KC_NC] = (int)(unsigned)total; piece_first[KC_NC] = (int)(unsigned)(total >> 32);
+        hdr->magic = KC_MAGIC; hdr->wh = wh; hdr->n = n; hdr->k = k; hdr->npieces = (int)(unsigned)(total >> 32);
     }
 }
 __global__ __launch_bounds__(256) void k_kc_pieces(const int *__restrict__ tot, const int *__restrict__ cell_start,
                                                    const int *__restrict__ piece_first, int *__restrict__ pcell, int *__restrict__ pstart,
-                                                   int *__restrict__ pcnt, uint8_t *__restrict__ plab)
+                                                   int *__restrict__ pcnt, uint8_t *__restrict__ plab, int plab0)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= KC_NC) return;
     const int t = tot[c], s = cell_start[c], p0 = piece_first[c];
     for (int j = 0; j * KC_PIECE < t; ++j) {
         pcell[p0 + j] = c; pstart[p0 + j] = s + j * KC_PIECE; pcnt[p0 + j] = t - j * KC_PIECE < KC_PIECE ? t - j * KC_PIECE : KC_PIECE;
-        plab[p0 + j] = 255;                                       // labels per box (the caller's, copied into slab)
+        plab[p0 + j] = (uint8_t)plab0;                            // KC_PER_BOX: the caller's labels, copied into slab; KC_UNSET: none yet
     }
 }
 // boxes (and the caller's current labels) into cell order: the slice's cursors start where its prefix says
@@ -835,7 +858,7 @@ __global__ __launch_bounds__(1024) void k_kc_scatter(const float2 *__restrict__ 
         const float2 b = wh[i];
         const int at = atomicAdd(&kc_h[kc_cell(b)], 1);
         swh[at] = b;
-        slab[at] = labels[i];
+        if (labels) slab[at] = labels[i];
     }
 }
 // one wave per piece: its fixed-point sums of w and h (the values k_kmeans_step would add box by box)
@@ -983,10 +1006,12 @@ __global__ __launch_bounds__(KM_BLOCK) void k_kc_iter(const KcHdr *__restrict__ 
             atomicAdd(&sacc[(L * 2 + 0) * KM_BLOCK], (unsigned long long)ps0 + (unsigned long long)pc * KM_MAGIC);
             atomicAdd(&sacc[(L * 2 + 1) * KM_BLOCK], (unsigned long long)ps1 + (unsigned long long)pc * KM_MAGIC);
             atomicAdd(&scnt[L * KM_BLOCK], (unsigned)pc);
-            if (prevl == 255u) {                                   // its boxes were labelled one by one last time
-                int ch_ = 0;
-                for (int j = 0; j < pc; ++j) ch_ += slab[pst + j] != (uint8_t)L;
-                changed += ch_;
+            if (prevl == 255u) {
+                // its boxes were labelled one by one last time: how many of them change is counted by a whole wave below (the
+                // queue entry says "count only"); this lane alone over 256 bytes was the longest thing in the launch whenever
+                // the centroids still moved -- 24 us per iteration in a fit against 13 for the same launch at the fixed point
+                const int at = atomicAdd(&s_qn, 1);
+                s_queue[at] = tid; s_qstart[at] = pst; s_qcnt[at] = pc | (L << 16) | KC_Q_COUNT;
             } else if (prevl != (unsigned)L) {
                 changed += pc;
             }
@@ -1003,7 +1028,15 @@ __global__ __launch_bounds__(KM_BLOCK) void k_kc_iter(const KcHdr *__restrict__ 
         const int owner = s_queue[qi];
         const int qp = owner * (int)gridDim.x + (int)blockIdx.x;
         const int qs = s_qstart[qi], qc = s_qcnt[qi] & 0xffff;
-        const unsigned ql = (unsigned)s_qcnt[qi] >> 16;
+        const unsigned ql = ((unsigned)s_qcnt[qi] >> 16) & 0xffu;
+        if (s_qcnt[qi] & KC_Q_COUNT) {                             // decided as a whole (label ql): only the changed count is open
+#pragma unroll
+            for (int j = 0; j < KC_PIECE / 64; ++j) {
+                const int o = lane + 64 * j;
+                if (o < qc) changed += (unsigned)slab[qs + o] != ql;
+            }
+            continue;
+        }
 #pragma unroll
         for (int j = 0; j < KC_PIECE / 64; ++j) {
             const int o = lane + 64 * j;
@@ -1136,10 +1169,9 @@ __global__ __launch_bounds__(KM_BLOCK) void k_kc_persist(KcHdr *__restrict__ hdr
                 atomicAdd(&sacc[(L * 2 + 0) * KM_BLOCK], (unsigned long long)ps0 + (unsigned long long)pc * KM_MAGIC);
                 atomicAdd(&sacc[(L * 2 + 1) * KM_BLOCK], (unsigned long long)ps1 + (unsigned long long)pc * KM_MAGIC);
                 atomicAdd(&scnt[L * KM_BLOCK], (unsigned)pc);
-                if (prevl == 255u) {
-                    int ch_ = 0;
-                    for (int j = 0; j < pc; ++j) ch_ += slab[pst + j] != (uint8_t)L;
-                    changed += ch_;
+                if (prevl == 255u) {                               // counted by a wave below, as in k_kc_iter
+                    const int at = atomicAdd(&s_qn, 1);
+                    s_queue[at] = tid; s_qstart[at] = pst; s_qcnt[at] = pc | (L << 16) | KC_Q_COUNT;
                 } else if (prevl != (unsigned)L) {
                     changed += pc;
                 }
@@ -1154,7 +1186,15 @@ __global__ __launch_bounds__(KM_BLOCK) void k_kc_persist(KcHdr *__restrict__ hdr
         const int qn = s_qn;
         for (int qi = wave; qi < qn; qi += KM_BLOCK / 64) {
             const int qs = s_qstart[qi], qc = s_qcnt[qi] & 0xffff;
-            const unsigned ql = (unsigned)s_qcnt[qi] >> 16;
+            const unsigned ql = ((unsigned)s_qcnt[qi] >> 16) & 0xffu;
+            if (s_qcnt[qi] & KC_Q_COUNT) {
+#pragma unroll
+                for (int j = 0; j < KC_PIECE / 64; ++j) {
+                    const int o = lane + 64 * j;
+                    if (o < qc) changed += (unsigned)slab[qs + o] != ql;
+                }
+                continue;
+            }
 #pragma unroll
             for (int j = 0; j < KC_PIECE / 64; ++j) {
                 const int o = lane + 64 * j;
@@ -1270,21 +1310,23 @@ extern "C" size_t dg_kmeans_prepared_workspace_bytes(int64_t n, int64_t k)
 extern "C" int dg_kmeans_prepare(const float *wh, int64_t n, int64_t k, const uint8_t *labels, void *ws, size_t ws_bytes, dg_stream_t s)
 {
     DG_REQUIRE(n >= 1 && n < (1ll << 31) && k >= 1 && k <= 16, "kmeans_prepare: need 1 <= n < 2^31 and 1 <= k <= 16");
-    DG_REQUIRE(wh && labels && (((uintptr_t)wh) & 7) == 0, "kmeans_prepare: null or misaligned pointer");
+    DG_REQUIRE(wh && (((uintptr_t)wh) & 7) == 0, "kmeans_prepare: null or misaligned pointer");
     DG_REQUIRE(ws && (((uintptr_t)ws) & 255) == 0, "kmeans_prepare: workspace null or not 256-byte aligned");
     if (ws_bytes < dg_kmeans_prepared_workspace_bytes(n, k)) { dg_set_error("kmeans_prepare: workspace too small"); return DG_ENOMEM; }
     hipStream_t st = (hipStream_t)s;
     KcWs w = kc_layout(n, k, ws);
     const size_t lds = (size_t)KC_NC * 4;
     if (hipFuncSetAttribute((const void *)k_kc_hist, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute((const void *)k_kc_scan, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
         hipFuncSetAttribute((const void *)k_kc_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         dg_set_error("kmeans_prepare: cannot raise the LDS limit"); return DG_EHIP;
     }
     if (hipMemsetAsync(w.pcnt, 0, (size_t)w.pmax * 4, st) != hipSuccess) { dg_set_error("kmeans_prepare: memset failed"); return DG_EHIP; }
     hipLaunchKernelGGL(k_kc_hist, dim3(KC_G), dim3(1024), lds, st, (const float2 *)wh, (long long)n, w.counts);
     hipLaunchKernelGGL(k_kc_colscan, dim3((KC_NC + 255) / 256), dim3(256), 0, st, w.counts, w.tot);
-    hipLaunchKernelGGL(k_kc_scan, dim3(1), dim3(1024), 0, st, w.tot, w.cell_start, w.piece_first, w.hdr, (const void *)wh, (long long)n, (int)k);
-    hipLaunchKernelGGL(k_kc_pieces, dim3((KC_NC + 255) / 256), dim3(256), 0, st, w.tot, w.cell_start, w.piece_first, w.pcell, w.pstart, w.pcnt, w.plab);
+    hipLaunchKernelGGL(k_kc_scan, dim3(1), dim3(1024), lds, st, w.tot, w.cell_start, w.piece_first, w.hdr, (const void *)wh, (long long)n, (int)k);
+    hipLaunchKernelGGL(k_kc_pieces, dim3((KC_NC + 255) / 256), dim3(256), 0, st, w.tot, w.cell_start, w.piece_first, w.pcell, w.pstart, w.pcnt, w.plab,
+                       labels ? KC_PER_BOX : KC_UNSET);
     hipLaunchKernelGGL(k_kc_scatter, dim3(KC_G), dim3(1024), lds, st, (const float2 *)wh, labels, (long long)n, w.counts, w.cell_start, w.swh, w.slab);
     hipLaunchKernelGGL(k_kc_piecesums, dim3((unsigned)((w.pmax + 3) / 4)), dim3(256), 0, st, w.swh, w.pstart, w.pcnt, w.hdr, w.psum, w.pbox);
     DG_CHECK_LAUNCH("kmeans_prepare");
