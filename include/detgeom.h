@@ -231,7 +231,11 @@ int dg_kmeans_labels_i32(const uint8_t *labels, int64_t n, int32_t *out, dg_stre
  * bound to the CONTENTS of wh and to the labels as they were at prepare time: prepare again when either changes behind the
  * library's back (labels written by dg_kmeans_iou_run_prepared itself are tracked).  labels == NULL says that no box has a
  * label yet (what a fit starts from: every box then counts as changed by the first iteration, exactly as an array of 255s
- * would make it) and saves moving n label bytes one by one.  ws 256-byte aligned. */
+ * would make it) and saves moving n label bytes one by one.  dg_kmeans_iou_run_prepared with labels == NULL runs the
+ * iterations over cells only: centroids and history as always, but no final pass over the boxes in their own order, so no
+ * labels, no inertia, no acc (which may then be NULL as well) -- for the intermediate chunks of a fit that runs until no label
+ * changes; once an iteration has changed nothing, one dg_kmeans_iou_step at the centroids as they stand gives the labels,
+ * the inertia and acc that the full call would have given.  ws 256-byte aligned. */
 size_t dg_kmeans_prepared_workspace_bytes(int64_t n, int64_t k);
 int dg_kmeans_prepare(const float *wh, int64_t n, int64_t k, const uint8_t *labels, void *ws, size_t ws_bytes, dg_stream_t s);
 int dg_kmeans_iou_run_prepared(const float *wh, int64_t n, float *cent, int64_t k, uint8_t *labels, int64_t *acc,

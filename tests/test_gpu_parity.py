@@ -1150,6 +1150,24 @@ def test_kmeans_prepared_fit_vs_oracle(va, oracle, n, k, iters, monkeypatch):
         assert list(e._backend.history_host(3)) == hist[iters:iters + 3]
 
 
+@pytest.mark.parametrize("max_iter", [5, 20, 40])
+def test_kmeans_prepared_fit_stopped_by_max_iter_vs_oracle(va, oracle, max_iter, monkeypatch):
+    """A fit that runs until nothing changes issues its intermediate chunks over cells only (no pass over the boxes: dg_kmeans_iou_run_prepared
+    with labels NULL) and growing (8, 8, 16, 32 iterations); one that max_iter stops short of convergence must still end in a full
+    chunk: labels and inertia of the LAST iteration's assignment (against the centroids before the last update), as the oracle's loop."""
+    from vision_amd import cluster
+    n = 250000
+    wh = wl.anchor_wh(5, n)
+    x = torch.from_numpy(wh).cuda()
+    monkeypatch.setenv("DG_KMEANS_CELLS", "1")
+    km = cluster.kmean(5, 42, max_iter=max_iter).fit(x)
+    assert km._backend.cells is not None
+    cent, labels, n_iter, inertia = oracle.kmeans_fit(wh, 5, 42, max_iter=max_iter)
+    assert n_iter == max_iter == km.n_iter_                       # this set needs more than 40 iterations
+    assert np.array_equal(km.cluster_centers_.view(np.uint32), cent.view(np.uint32))
+    assert np.array_equal(km.labels_, labels) and abs(km.inertia_ - inertia) < 1e-9
+
+
 def test_kmeans_sharded_equals_single(va, oracle):
     """fake all-reduce: shards stepped one after another on one device, integer partial sums added."""
     from vision_amd import ops

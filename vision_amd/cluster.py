@@ -24,6 +24,7 @@ import torch.distributed as dist
 from . import _abi, ops
 
 _CHUNK = 8          # iterations launched between two host checks of the changed-count history
+_CHUNK_MAX = 32     # the prepared fit's chunks grow (8, 8, 16, 32, 32, ...) -- the end of a chunk costs what seven of its iterations do
 _CELLS_MIN_BOXES = 200_000   # single-device fits of at least this many boxes take the prepared (cell) path
 
 
@@ -110,13 +111,15 @@ class _HipBackend:
                                                      None if fresh else _abi.ptr(self.labels),
                                                      _abi.ptr(self.cells[0]), self.cells[1], _abi.stream_ptr(dev)))
 
-    def run_local(self, slot0, iters):
-        """single device: `iters` launches issued by one C call (dg_kmeans_iou_run)"""
+    def run_local(self, slot0, iters, light=False):
+        """single device: `iters` launches issued by one C call (dg_kmeans_iou_run).  light (prepared fit only): the iterations
+        over cells alone -- centroids and history, no labels / inertia / acc (include/detgeom.h)"""
         dev = self.wh.device
         if self.cells is not None:
             with torch.cuda.device(dev):
                 _abi.check(_abi.load().dg_kmeans_iou_run_prepared(_abi.ptr(self.wh), self.wh.shape[0], _abi.ptr(self.cent),
-                                                                  self.cent.shape[0], _abi.ptr(self.labels), _abi.ptr(self.acc),
+                                                                  self.cent.shape[0], None if light else _abi.ptr(self.labels),
+                                                                  None if light else _abi.ptr(self.acc),
                                                                   _abi.ptr(self.history), slot0, iters, _abi.ptr(self.cells[0]),
                                                                   self.cells[1], _abi.stream_ptr(dev)))
             return
@@ -281,18 +284,31 @@ class kmean:
         iters = fixed_iters if fixed_iters is not None else self.max_iter
         be = self._backend
         self._graphs = {}
-        be.prepare(X, init_centers, k, min(iters, _CHUNK) if fixed_iters is None else iters,
-                   cells=False if self._is_sharded() else None)
+        sharded = self._is_sharded()
+        be.prepare(X, init_centers, k, min(iters, _CHUNK if sharded else max(_CHUNK, _CHUNK_MAX)) if fixed_iters is None else iters,
+                   cells=False if sharded else None)
         done, n_iter = 0, 0
         while done < iters:
-            chunk = min(_CHUNK if fixed_iters is None else iters, iters - done)
+            # one device: a chunk ends in an iteration over the boxes (labels, inertia), two small launches and a read-back of the
+            # history -- about 0.1 ms, seven prepared iterations -- while an iteration past convergence costs one: the chunks
+            # grow (8, 8, 16, 32, 32, ...).  The box loop's chunk ends in a read-back only and its iterations cost twice as much:
+            # fixed chunks (measured: growing ones 5.2 -> 5.3 ms for 156 iterations); sharded: fixed too (one captured graph)
+            prepared = getattr(be, "cells", None) is not None
+            grow = _CHUNK if not prepared or done < 2 * _CHUNK else (2 * _CHUNK if done < 4 * _CHUNK else max(_CHUNK, _CHUNK_MAX))
+            chunk = min(grow if fixed_iters is None else iters, iters - done)
+            # a prepared chunk that cannot be the fit's last one (iterations remain after it) skips the pass over the boxes: if
+            # it turns out to hold the first iteration that changes nothing, the centroids have stopped moving and one plain step
+            # at them gives the labels and the inertia that the chunk's last iteration would have given
+            light = prepared and fixed_iters is None and done + chunk < iters
             # a converged iteration (changed == 0) recomputes identical centroids, so running the
             # rest of the chunk is idempotent; every chunk writes history[0:chunk], read back here.
-            self._run_iters(0, chunk)
+            self._run_iters(0, chunk, light=light)
             if fixed_iters is None:
                 z = np.nonzero(be.history_host(chunk) == 0)[0]
                 if z.size:
                     n_iter = done + int(z[0]) + 1
+                    if light:
+                        be.step()
                     break
             done += chunk
             n_iter = done
@@ -387,11 +403,14 @@ class kmean:
         else:
             self.graph_state = {2: "captured", 1: "armed"}.get(comm.graph_state(), "eager: " + _abi.last_error())
 
-    def _run_iters(self, slot0, count):
+    def _run_iters(self, slot0, count, light=False):
         """`count` Lloyd iterations, asynchronous on the current stream (history slots slot0..slot0+count-1)."""
         be = self._backend
         if not self._is_sharded():
-            be.run_local(slot0, count)
+            if light:
+                be.run_local(slot0, count, light=True)
+            else:
+                be.run_local(slot0, count)
             return
         comm = self._so_comm()
         if comm is not None:

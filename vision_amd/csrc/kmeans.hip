@@ -1361,9 +1361,15 @@ extern "C" int dg_kmeans_iou_run_prepared(const float *wh, int64_t n, float *cen
                                           int64_t *history, int64_t slot0, int64_t iters, void *ws, size_t ws_bytes, dg_stream_t s)
 {
     DG_REQUIRE(iters >= 0, "kmeans_run_prepared: iters < 0");
-    int rc = km_check("kmeans_run_prepared", wh, n, cent, k, labels);
+    // labels == NULL: the cell iterations only -- centroids and history as always, but no pass over the boxes in their own
+    // order at the end, hence no labels, no inertia and no acc (which may be NULL too).  For the chunks of a fit that runs
+    // until nothing changes: only its last chunk's results are ever looked at, and once an iteration has changed nothing
+    // one dg_kmeans_iou_step with the centroids as they stand gives exactly those results.
+    const bool light = labels == nullptr;
+    static const uint8_t no_labels = 0;
+    int rc = km_check("kmeans_run_prepared", wh, n, cent, k, light ? &no_labels : labels);
     if (rc) return rc;
-    DG_REQUIRE(acc && n >= 1, "kmeans_run_prepared: null acc or no boxes");
+    DG_REQUIRE((acc || light) && n >= 1, "kmeans_run_prepared: null acc or no boxes");
     DG_REQUIRE(ws && (((uintptr_t)ws) & 255) == 0, "kmeans_run_prepared: workspace null or not 256-byte aligned");
     if (ws_bytes < dg_kmeans_prepared_workspace_bytes(n, k)) { dg_set_error("kmeans_run_prepared: workspace too small"); return DG_ENOMEM; }
     if (iters == 0) return DG_OK;
@@ -1402,14 +1408,16 @@ extern "C" int dg_kmeans_iou_run_prepared(const float *wh, int64_t n, float *cen
     }
     for (int64_t t = t0; t < iters; ++t) {
         const long long *prev = (t && !t0) ? w.part[(t - 1) % 3] : nullptr;
-        if (t + 1 == iters) {
+        if (t + 1 == iters && !light) {
             // the last iteration twice from the same centroids: box order for labels / inertia / acc, cells for `changed`
             if ((rc = km_launch(wh, n, cent, k, labels, (const int64_t *)prev, (int64_t *)w.part[3], nullptr, history, slot0 + t - 1, true, st))) return rc;
             if ((rc = kc_launch(w, cent, k, prev, w.part[t % 3], nullptr, nullptr, 0, 0, st))) return rc;
         } else {
-            if ((rc = kc_launch(w, cent, k, prev, w.part[t % 3], w.part[(t + 1) % 3], history, slot0 + t - 1, 1, st))) return rc;
+            if ((rc = kc_launch(w, cent, k, prev, w.part[t % 3], t + 1 < iters ? w.part[(t + 1) % 3] : nullptr, history, slot0 + t - 1, 1, st))) return rc;
         }
     }
+    if (light)                                                    // fold the last iteration: centroids, its changed count
+        return km_finish((const int64_t *)w.part[(iters - 1) % 3], k, cent, nullptr, history, slot0 + iters - 1, st);
     if ((rc = km_finish((const int64_t *)w.part[3], k, cent, acc, nullptr, 0, st))) return rc;
     hipLaunchKernelGGL(k_kc_changed, dim3(1), dim3(1), 0, st, w.part[(iters - 1) % 3], (int)k, (long long *)acc, (long long *)history, slot0 + iters - 1);
     DG_CHECK_LAUNCH("k_kc_changed");
