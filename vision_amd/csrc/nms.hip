@@ -52,7 +52,7 @@ struct NmsWs {
     struct NmsHdr *hdr;
     float4 *bbox;
     float2 *bar;
-    int32_t *pos, *start;
+    int32_t *posu, *start;   // position in x-bucket order by the caller's index (found beside the chunk sort), bucket starts
     u64 *diag;
     int64_t lcap;            // entries each of an image's 64 pair lists (and 64 work lists) holds: they share the image's dense mask
     int lsh;                 // a pair's list: higher rank >> lsh
@@ -99,13 +99,13 @@ static NmsWs nms_layout(int64_t batch, int64_t nmax, void *base)
         w.hdr = (struct NmsHdr *)take((size_t)batch * 64);
         w.bbox = (float4 *)take((size_t)batch * w.Np * 16);
         w.bar = (float2 *)take((size_t)batch * w.Np * 8);
-        w.pos = (int32_t *)take((size_t)batch * w.Np * 4);
+        w.posu = (int32_t *)take((size_t)batch * w.Np * 4);
         w.start = (int32_t *)take((size_t)batch * (4096 + 1) * 4);       // XB_G + 1
         w.diag = (u64 *)take((size_t)batch * w.Np * 8);
         w.lcnt = (int32_t *)take((size_t)batch * 64 * 32 * 4);           // LC_STRIDE
         w.mc = (u32 *)take((size_t)batch * 4352 * 4);                    // MC_WORDS
     } else {
-        w.hdr = nullptr; w.bbox = nullptr; w.bar = nullptr; w.pos = nullptr; w.start = nullptr; w.diag = nullptr;
+        w.hdr = nullptr; w.bbox = nullptr; w.bar = nullptr; w.posu = nullptr; w.start = nullptr; w.diag = nullptr;
         w.lcnt = nullptr; w.mc = nullptr;
     }
     w.total = off;
@@ -209,6 +209,132 @@ __global__ __launch_bounds__(256) void k_bitonic_global(u64 *__restrict__ keys, 
     if ((a > b) == asc) { g[i] = b; g[l] = a; }
 }
 
+// ---------------------------------------------------------------- x-bucket order of one image (pruned path, see k_nms_band)
+#define XB_G 4096
+__device__ __forceinline__ int xb_bucket(float x, float xmin, float scale)
+{
+    return (int)fminf(fmaxf((x - xmin) * scale, 0.0f), (float)(XB_G - 1));      // monotone in x; a NaN product (inf * 0) -> 0
+}
+
+// One workgroup of 1024 threads per image (n <= 65536: at most 64 boxes per thread): range of the left edges and non-finite
+// boxes, bucket histogram in LDS, scan, every box's position in x-bucket order.  (Global-memory atomics are not an option here:
+// device-scope atomics are carried out at the memory side on this part, about 8 ns each on one address -- a grid-wide histogram
+// of 131 k of them took 25 us.)  The candidate-pair count that decides between this path and the dense mask is estimated from
+// 1024 boxes spread over the image.
+// It works on the boxes AS THE CALLER GAVE THEM (position by the caller's index, `posu`), not on the score-sorted copy: nothing in
+// it depends on the ranks, so it runs as one more workgroup of k_nms_sort_chunks' launch, beside the 2..16 workgroups that sort
+// the score keys, instead of as a launch of its own behind k_nms_merge_rank (22-26 us of a 64 k-box call's 185);
+// k_nms_merge_rank, which knows both a box's index and its rank, carries the position over (`pos`, by rank).
+// s_hist: XB_G ints, s_start: XB_G + 1 (the sort's key buffer, which this workgroup does not use otherwise).
+__device__ __forceinline__ void xbucket_image(const float4 *__restrict__ bx, int n, int64_t Np, int force, NmsHdr *__restrict__ h,
+                                              int32_t *__restrict__ gs, int32_t *__restrict__ posu, int32_t *__restrict__ lcnt_img,
+                                              int *__restrict__ s_hist, int *__restrict__ s_start)
+{
+    __shared__ float s_mn[16], s_mx[16];
+    __shared__ int s_bad[16], s_part[16];
+    __shared__ unsigned long long s_cand;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < 64) lcnt_img[tid * LC_STRIDE] = 0;                  // the image's pair lists start empty
+    float mn = INFINITY, mx = -INFINITY;
+    int bad = 0;
+    // a thread's boxes: tid, tid + 1024, ... (at most 64), sixteen loads in flight
+#pragma unroll 1
+    for (int k0 = 0; k0 < 64 && tid + 1024 * k0 < n; k0 += 16) {
+        float4 b[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = tid + 1024 * (k0 + u);
+            b[u] = i < n ? bx[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = tid + 1024 * (k0 + u);
+            if (i < n) {                                          // a non-finite coordinate makes the area inf or NaN
+                mn = fminf(mn, b[u].x); mx = fmaxf(mx, b[u].x); bad |= !(dg_area(b[u].x, b[u].y, b[u].z, b[u].w) < INFINITY);
+            }
+        }
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) { mn = fminf(mn, __shfl_xor(mn, d, 64)); mx = fmaxf(mx, __shfl_xor(mx, d, 64)); bad |= __shfl_xor(bad, d, 64); }
+    if (lane == 0) { s_mn[wave] = mn; s_mx[wave] = mx; s_bad[wave] = bad; }
+    for (int t = tid; t < XB_G; t += 1024) s_hist[t] = 0;
+    if (tid == 0) s_cand = 0ull;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) { mn = fminf(mn, s_mn[k]); mx = fmaxf(mx, s_mx[k]); bad |= s_bad[k]; }
+    if (bad || force == 0 || n <= 64) {                           // uniform
+        if (tid == 0) { h->xmin = 0.f; h->scale = 0.f; h->mode = 1; h->fpdone = 0; h->rounds = 0; h->npairs = 0; h->cpb = 0; h->estsum = 0u; }
+        return;
+    }
+    const float range = mx - mn;
+    float scale = (float)XB_G / range;
+    if (!(range > 0.0f) || !(scale < INFINITY)) scale = 0.0f;    // everything in bucket 0: the candidate count then says "dense"
+    // ONE pass of LDS atomics: the add that counts a box also tells its place inside its bucket; bucket (12 bits) and place
+    // (20 bits) wait in registers (64 per thread, every index static) until the bucket starts are known.  (A counting pass and
+    // a second, returning pass over the boxes read again took 25 us for 64 k boxes, two thirds of it the 131 k atomics.)
+    u32 packed[64];
+#pragma unroll
+    for (int k0 = 0; k0 < 64; k0 += 16) {
+        float xv[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = tid + 1024 * (k0 + u);
+            xv[u] = i < n ? bx[i].x : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int i = tid + 1024 * (k0 + u);
+            u32 pk = 0u;
+            if (i < n) {
+                const int bk = xb_bucket(xv[u], mn, scale);
+                pk = ((u32)bk << 20) | (u32)atomicAdd(&s_hist[bk], 1);           // (a bucket holds at most n <= 65536 < 2^20 boxes)
+            }
+            packed[k0 + u] = pk;
+        }
+    }
+    __syncthreads();
+    {   // exclusive scan of the 4096 counts: four per thread, wave scan, 16 wave totals
+        const int c0 = s_hist[4 * tid], c1 = s_hist[4 * tid + 1], c2 = s_hist[4 * tid + 2], c3 = s_hist[4 * tid + 3];
+        const int mine = c0 + c1 + c2 + c3;
+        int incl = mine;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
+        if (lane == 63) s_part[wave] = incl;
+        __syncthreads();
+        int base = 0;
+        for (int k = 0; k < wave; ++k) base += s_part[k];
+        int e = base + incl - mine;
+        s_start[4 * tid] = e; gs[4 * tid] = e; e += c0;
+        s_start[4 * tid + 1] = e; gs[4 * tid + 1] = e; e += c1;
+        s_start[4 * tid + 2] = e; gs[4 * tid + 2] = e; e += c2;
+        s_start[4 * tid + 3] = e; gs[4 * tid + 3] = e;
+        if (tid == 0) { s_start[XB_G] = n; gs[XB_G] = n; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 64; ++k) {
+        const int i = tid + 1024 * k;
+        if (i < n) posu[i] = s_start[packed[k] >> 20] + (int)(packed[k] & 0xfffffu);
+    }
+    {   // one sampled box per thread, spread over the image: the boxes whose left edge may lie inside its x range
+        const int i = (int)(((long long)tid * n) >> 10);
+        const float4 sb = bx[i];
+        const int c = s_start[xb_bucket(fmaxf(sb.x, sb.z), mn, scale) + 1] - s_start[xb_bucket(sb.x, mn, scale)];
+        unsigned long long cand = (unsigned long long)(c > 0 ? c : 0);
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) cand += __shfl_xor(cand, d, 64);
+        if (lane == 0) atomicAdd(&s_cand, cand);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        // candidates per box ~ s_cand / 1024; the band kernel tests about 1.8 x as many pairs (a row tile runs to the end of
+        // its widest box), the dense mask n / 2 per box
+        const bool prune = force == 2 || s_cand * 4ull <= 1024ull * (unsigned long long)n;
+        h->xmin = mn; h->scale = scale; h->mode = prune ? 0 : 1; h->fpdone = 0; h->rounds = 0; h->npairs = 0;
+        h->cpb = (int32_t)(s_cand >> 10); h->estsum = 0u;
+    }
+}
+
 // ---------------------------------------------------------------- sort, 4096 < n <= 65536: sorted chunks + rank merge
 // Two launches instead of the bitonic network's 17 (for 64 k keys about 100 us, most of it launch-to-launch): every
 // SORT_CHUNK of keys is built and sorted in LDS (ascending), then each key finds its final rank directly -- its place in its
@@ -216,16 +342,24 @@ __global__ __launch_bounds__(256) void k_bitonic_global(u64 *__restrict__ keys, 
 // 64 block maxima in LDS, 6 inside one 64-key block in memory; equal keys -- the padding -- go by chunk order) -- and the
 // box is gathered straight to that rank.
 __global__ __launch_bounds__(1024) void k_nms_sort_chunks(const float *__restrict__ scores, const int32_t *__restrict__ counts,
-                                                          int64_t nmax, int64_t Np2, u64 *__restrict__ keys)
+                                                          int64_t nmax, int64_t Np2, u64 *__restrict__ keys,
+                                                          const float4 *__restrict__ boxes, int64_t Np, int force, NmsHdr *__restrict__ hdr,
+                                                          int32_t *__restrict__ start, int32_t *__restrict__ posu, int32_t *__restrict__ lcnt)
 {
     // Round 3, second form: the keys live in REGISTERS, four consecutive ones per thread (element 4 tid + r).  Of the 78
     // compare-exchange steps of the bitonic network, 23 have their partner in the same thread (j = 1, 2: no data movement),
     // 45 in the same wave (j = 4 .. 128 elements = 1 .. 32 lanes: a cross-lane exchange), and only 10 cross waves
     // (j >= 256: through LDS, two workgroup barriers each).  The LDS version before it made every step a round trip of
     // reads and conditional writes (15 of them with a barrier) and took 31 us for 64 k keys on its 16 workgroups.
-    __shared__ __attribute__((aligned(16))) u64 s[SORT_CHUNK];
+    __shared__ __attribute__((aligned(16))) u64 s[SORT_CHUNK + 8];
     const int tid = threadIdx.x, img = blockIdx.y;
     const int n = counts ? counts[img] : (int)nmax;
+    if ((int64_t)blockIdx.x * SORT_CHUNK >= Np2) {
+        // the launch's extra workgroup (pruned path only): the image's x-bucket order, from the caller's boxes (xbucket_image)
+        xbucket_image(boxes + (int64_t)img * nmax, n, Np, force, hdr + img, start + (int64_t)img * (XB_G + 1), posu + (int64_t)img * Np,
+                      lcnt + (int64_t)img * 64 * LC_STRIDE, (int *)s, (int *)s + XB_G);
+        return;
+    }
     const int64_t base = (int64_t)blockIdx.x * SORT_CHUNK;
     u64 *g = keys + (int64_t)img * Np2 + base;
     u64 v[4];
@@ -286,7 +420,9 @@ __global__ __launch_bounds__(1024) void k_nms_sort_chunks(const float *__restric
 
 __global__ __launch_bounds__(256) void k_nms_merge_rank(const float4 *__restrict__ boxes, const u64 *__restrict__ keys,
                                                         const int32_t *__restrict__ counts, int64_t nmax, int64_t Np, int64_t Np2,
-                                                        float *x1, float *y1, float *x2, float *y2, float *area, int32_t *order)
+                                                        float *x1, float *y1, float *x2, float *y2, float *area, int32_t *order,
+                                                        const int32_t *__restrict__ posu, const NmsHdr *__restrict__ hdr,
+                                                        const int32_t *__restrict__ start, float4 *__restrict__ bbox, float2 *__restrict__ bar)
 {
     __shared__ u64 s_max[16][64];                                 // last key of every 64-key block of every chunk
     const int img = blockIdx.y, tid = threadIdx.x;
@@ -330,7 +466,31 @@ __global__ __launch_bounds__(256) void k_nms_merge_rank(const float4 *__restrict
     for (int cc = 0; cc < 16; ++cc)
         if (cc < nchunks && cc != c) rank += blk[cc] * 64 + in[cc];
     // (inside a block the search covers offsets 0 .. 62 + one more step: the block's last key is not before K, or blk would be larger)
-    if (rank < Np) gather_sorted(boxes + (int64_t)img * nmax, K, rank < n, (int64_t)img * Np + rank, x1, y1, x2, y2, area, order);
+    if (rank < Np) {
+        // gather_sorted, and for an image of the pruned path (hdr.mode == 0) the box also goes to its place in x-bucket order --
+        // found by index beside the chunk sort (xbucket_image); the zero boxes of the padding stay behind the real ones -- as
+        // bbox = corners, bar = {area, rank}.  With the rank (< 65536) goes the last 64-box tile of that order that can hold a
+        // partner of this box: the one where the bucket of its right edge ends.  (Was a launch of its own, k_nms_xb_scatter.)
+        const bool valid = rank < n;
+        const int64_t o = (int64_t)img * Np;
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        int32_t idx = 0;
+        if (valid) { idx = (int32_t)(u32)K; b = boxes[(int64_t)img * nmax + idx]; }
+        const float ar = dg_area(b.x, b.y, b.z, b.w);
+        x1[o + rank] = b.x; y1[o + rank] = b.y; x2[o + rank] = b.z; y2[o + rank] = b.w;
+        area[o + rank] = ar;
+        order[o + rank] = idx;
+        if (posu && hdr[img].mode == 0) {
+            const NmsHdr *h = hdr + img;
+            int p = rank, endtile = 0;
+            if (valid) {
+                p = posu[o + idx];
+                endtile = (start[(int64_t)img * (XB_G + 1) + xb_bucket(fmaxf(b.x, b.z), h->xmin, h->scale) + 1] - 1) >> 6;
+            }
+            bbox[o + p] = b;
+            bar[o + p] = make_float2(ar, __int_as_float(rank | (endtile << 16)));
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void k_nms_gather(const float4 *__restrict__ boxes, const u64 *__restrict__ keys,
@@ -1422,179 +1582,17 @@ __global__ __launch_bounds__(1024) void k_nms_reduce_csr(const u64 *__restrict__
 // row tile instead of 513 on average).  Every suppressing pair is found exactly once (position order is a total order) and
 // emitted as a compact entry (lower rank's row in its 64-row block << 16 | word of the higher rank, one bit) into the lower
 // rank's block segment -- the form k_nms_reduce_csr consumes -- so the 512 MiB mask is neither written nor read.
-//   k_nms_xbucket : one workgroup per image: min/max of x1, non-finite boxes (-> dense path), histogram, scan, each box's
-//                   position; the exact number of candidate pairs decides between this path and the dense mask (hdr.mode);
-//   k_nms_xb_scatter: boxes into x-bucket order (bbox = corners, bar = {area, rank});
+//   xbucket_image : one workgroup per image, launched as an extra workgroup of k_nms_sort_chunks (it needs no ranks): min/max of
+//                   x1, non-finite boxes (-> dense path), histogram, scan, each box's position by the caller's index; the
+//                   estimated number of candidate pairs decides between this path and the dense mask (hdr.mode);
+//   k_nms_merge_rank: besides the score-sorted copy, the boxes into x-bucket order (bbox = corners, bar = {area, rank});
 //   k_nms_band    : the pair search;
 //   k_nms_resolve_mc: the greedy keep list as a fixed point instead of a serial chain (below).
-#define XB_G 4096
 #define BAND_STAGE 256
 #ifndef BAND_ROWS
 #define BAND_ROWS 8      // rows of a tile per pass of k_nms_band's row loop
 #endif
-__device__ __forceinline__ int xb_bucket(float x, float xmin, float scale)
-{
-    return (int)fminf(fmaxf((x - xmin) * scale, 0.0f), (float)(XB_G - 1));      // monotone in x; a NaN product (inf * 0) -> 0
-}
-
-// One workgroup per image (n <= 65536: at most 64 boxes per thread, their left edges stay in registers): range of the left
-// edges and non-finite boxes, bucket histogram in LDS, scan, every box's position in x-bucket order.  (Global-memory
-// atomics are not an option here: device-scope atomics are carried out at the memory side on this part, about 8 ns each
-// on one address -- a grid-wide histogram of 131 k of them took 25 us.)  The candidate-pair count that decides between this
-// path and the dense mask is estimated from 1024 boxes spread over the ranks.
-__global__ __launch_bounds__(1024) void k_nms_xbucket(const float *__restrict__ sx1, const float *__restrict__ sx2,
-                                                      const float *__restrict__ sarea, const int32_t *__restrict__ counts,
-                                                      int64_t nmax, int64_t Np, int force, NmsHdr *__restrict__ hdr,
-                                                      int32_t *__restrict__ start, int32_t *__restrict__ pos, int32_t *__restrict__ lcnt)
-{
-    __shared__ int s_hist[XB_G];
-    __shared__ int s_start[XB_G + 1];
-    __shared__ float s_mn[16], s_mx[16];
-    __shared__ int s_bad[16], s_part[16];
-    __shared__ unsigned long long s_cand;
-    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = counts ? counts[img] : (int)nmax;
-    const int64_t o = (int64_t)img * Np;
-    NmsHdr *h = hdr + img;
-    if (tid < 64) lcnt[(img * 64 + tid) * LC_STRIDE] = 0;                       // the image's pair lists start empty
-    float mn = INFINITY, mx = -INFINITY;
-    int bad = 0;
-    // a thread's boxes: the 16-byte chunks tid, tid + 1024, ... (four boxes each, at most 16 chunks), eight chunk loads in flight
-    const int nch = (n + 3) >> 2;
-#pragma unroll 1
-    for (int k0 = 0; k0 < 16 && tid + 1024 * k0 < nch; k0 += 8) {
-        float4 x[8], a[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int c = tid + 1024 * (k0 + u);
-            x[u] = c < nch ? *(const float4 *)(sx1 + o + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-            a[u] = c < nch ? *(const float4 *)(sarea + o + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = 4 * (tid + 1024 * (k0 + u));
-            const float xv[4] = {x[u].x, x[u].y, x[u].z, x[u].w}, av[4] = {a[u].x, a[u].y, a[u].z, a[u].w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (i + q < n) { mn = fminf(mn, xv[q]); mx = fmaxf(mx, xv[q]); bad |= !(av[q] < INFINITY); }   // a non-finite coordinate makes the area inf or NaN
-        }
-    }
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) { mn = fminf(mn, __shfl_xor(mn, d, 64)); mx = fmaxf(mx, __shfl_xor(mx, d, 64)); bad |= __shfl_xor(bad, d, 64); }
-    if (lane == 0) { s_mn[wave] = mn; s_mx[wave] = mx; s_bad[wave] = bad; }
-    for (int t = tid; t < XB_G; t += 1024) s_hist[t] = 0;
-    if (tid == 0) s_cand = 0ull;
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < 16; ++k) { mn = fminf(mn, s_mn[k]); mx = fmaxf(mx, s_mx[k]); bad |= s_bad[k]; }
-    if (bad || force == 0 || n <= 64) {                           // uniform
-        if (tid == 0) { h->xmin = 0.f; h->scale = 0.f; h->mode = 1; h->fpdone = 0; h->rounds = 0; h->npairs = 0; h->cpb = 0; h->estsum = 0u; }
-        return;
-    }
-    const float range = mx - mn;
-    float scale = (float)XB_G / range;
-    if (!(range > 0.0f) || !(scale < INFINITY)) scale = 0.0f;    // everything in bucket 0: the candidate count then says "dense"
-    // ONE pass of LDS atomics: the add that counts a box also tells its place inside its bucket; bucket (12 bits) and place
-    // (20 bits) wait in registers (64 per thread, every index static) until the bucket starts are known.  (A counting pass and
-    // a second, returning pass over the boxes read again took 25 us for 64 k boxes, two thirds of it the 131 k atomics.)
-    u32 packed[64];
-#pragma unroll
-    for (int k0 = 0; k0 < 16; k0 += 8) {
-        float4 x[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int c = tid + 1024 * (k0 + u);
-            x[u] = c < nch ? *(const float4 *)(sx1 + o + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = 4 * (tid + 1024 * (k0 + u));
-            const float xv[4] = {x[u].x, x[u].y, x[u].z, x[u].w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                u32 pk = 0u;
-                if (i + q < n) {
-                    const int bk = xb_bucket(xv[q], mn, scale);
-                    pk = ((u32)bk << 20) | (u32)atomicAdd(&s_hist[bk], 1);       // (a bucket holds at most n <= 65536 < 2^20 boxes)
-                }
-                packed[(k0 + u) * 4 + q] = pk;
-            }
-        }
-    }
-    __syncthreads();
-    {   // exclusive scan of the 4096 counts: four per thread, wave scan, 16 wave totals
-        const int c0 = s_hist[4 * tid], c1 = s_hist[4 * tid + 1], c2 = s_hist[4 * tid + 2], c3 = s_hist[4 * tid + 3];
-        const int mine = c0 + c1 + c2 + c3;
-        int incl = mine;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const int up = __shfl_up(incl, d, 64); if (lane >= d) incl += up; }
-        if (lane == 63) s_part[wave] = incl;
-        __syncthreads();
-        int base = 0;
-        for (int k = 0; k < wave; ++k) base += s_part[k];
-        int e = base + incl - mine;
-        int32_t *gs = start + (int64_t)img * (XB_G + 1);
-        s_start[4 * tid] = e; gs[4 * tid] = e; e += c0;
-        s_start[4 * tid + 1] = e; gs[4 * tid + 1] = e; e += c1;
-        s_start[4 * tid + 2] = e; gs[4 * tid + 2] = e; e += c2;
-        s_start[4 * tid + 3] = e; gs[4 * tid + 3] = e;
-        if (tid == 0) { s_start[XB_G] = n; gs[XB_G] = n; }
-    }
-    __syncthreads();
-    const int nchp = (int)(Np >> 2);
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-        const int c = tid + 1024 * k, i = 4 * c;
-        if (c < nchp) {
-            int pv[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)                              // the zero boxes of the padding stay behind the real ones
-                pv[q] = (i + q < n) ? s_start[packed[k * 4 + q] >> 20] + (int)(packed[k * 4 + q] & 0xfffffu) : i + q;
-            *(int4 *)(pos + o + i) = make_int4(pv[0], pv[1], pv[2], pv[3]);
-        }
-    }
-    {   // one sampled box per thread, spread over the ranks: the boxes whose left edge may lie inside its x range
-        const int i = (int)(((long long)tid * n) >> 10);
-        const float a = sx1[o + i], b = sx2[o + i];
-        const int c = s_start[xb_bucket(fmaxf(a, b), mn, scale) + 1] - s_start[xb_bucket(a, mn, scale)];
-        unsigned long long cand = (unsigned long long)(c > 0 ? c : 0);
-#pragma unroll
-        for (int d = 32; d > 0; d >>= 1) cand += __shfl_xor(cand, d, 64);
-        if (lane == 0) atomicAdd(&s_cand, cand);
-    }
-    __syncthreads();
-    if (tid == 0) {
-        // candidates per box ~ s_cand / 1024; the band kernel tests about 1.8 x as many pairs (a row tile runs to the end of
-        // its widest box), the dense mask n / 2 per box
-        const bool prune = force == 2 || s_cand * 4ull <= 1024ull * (unsigned long long)n;
-        h->xmin = mn; h->scale = scale; h->mode = prune ? 0 : 1; h->fpdone = 0; h->rounds = 0; h->npairs = 0;
-        h->cpb = (int32_t)(s_cand >> 10); h->estsum = 0u;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_nms_xb_scatter(const float *__restrict__ sx1, const float *__restrict__ sy1,
-                                                        const float *__restrict__ sx2, const float *__restrict__ sy2,
-                                                        const float *__restrict__ sarea, const int32_t *__restrict__ pos,
-                                                        const int32_t *__restrict__ start, const int32_t *__restrict__ counts,
-                                                        int64_t nmax, const NmsHdr *__restrict__ hdr, int64_t Np,
-                                                        float4 *__restrict__ bbox, float2 *__restrict__ bar)
-{
-    const int img = blockIdx.y;
-    const NmsHdr *h = hdr + img;
-    if (h->mode != 0) return;
-    const int n = counts ? counts[img] : (int)nmax;
-    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= Np) return;
-    const int64_t o = (int64_t)img * Np, p = o + pos[o + i];
-    const float a = sx1[o + i], b = sx2[o + i];
-    // with the rank (< 65536) goes the last 64-box tile of the x-bucket order that can hold a partner of this box: the one
-    // where the bucket of its right edge ends
-    int endtile = 0;
-    if (i < n) endtile = (start[(int64_t)img * (XB_G + 1) + xb_bucket(fmaxf(a, b), h->xmin, h->scale) + 1] - 1) >> 6;
-    bbox[p] = make_float4(a, sy1[o + i], b, sy2[o + i]);
-    bar[p] = make_float2(sarea[o + i], __int_as_float((int)i | (endtile << 16)));
-}
-
+// (XB_G, xb_bucket and the x-bucket order itself, xbucket_image: above, beside the chunk sort it runs with)
 // the mask phase on its own (dg_nms_phase_mask called again on a sorted workspace, as bench.py times it): the pair list starts empty
 __global__ void k_nms_reset_pairs(NmsHdr *__restrict__ hdr, int32_t *__restrict__ lcnt, int batch)
 {
@@ -2452,10 +2450,11 @@ case 512: launch_sort_small<512>(w, boxes, scores, counts, batch, nmax, st); bre
     case 2048: launch_sort_small<2048>(w, boxes, scores, counts, batch, nmax, st); break;
     case 4096: launch_sort_small<4096>(w, boxes, scores, counts, batch, nmax, st); break;
     case 8192: case 16384: case 32768: case 65536:
-        hipLaunchKernelGGL(k_nms_sort_chunks, dim3((unsigned)(w.Np2 / SORT_CHUNK), (unsigned)batch), dim3(1024), 0, st, scores, counts, nmax,
-                           w.Np2, w.keys);
+        // (pruned path: one more workgroup per image finds the x-bucket order beside the sort, see xbucket_image)
+        hipLaunchKernelGGL(k_nms_sort_chunks, dim3((unsigned)(w.Np2 / SORT_CHUNK) + (prune ? 1u : 0u), (unsigned)batch), dim3(1024), 0, st, scores,
+                           counts, nmax, w.Np2, w.keys, (const float4 *)boxes, w.Np, nms_prune_mode(), w.hdr, w.start, w.posu, w.lcnt);
         hipLaunchKernelGGL(k_nms_merge_rank, dim3((unsigned)(w.Np2 / 256), (unsigned)batch), dim3(256), 0, st, (const float4 *)boxes, w.keys,
-                           counts, nmax, w.Np, w.Np2, w.x1, w.y1, w.x2, w.y2, w.area, w.order);
+                           counts, nmax, w.Np, w.Np2, w.x1, w.y1, w.x2, w.y2, w.area, w.order, prune ? w.posu : nullptr, w.hdr, w.start, w.bbox, w.bar);
         break;
     default: {
         const int64_t Np2 = w.Np2;
@@ -2472,13 +2471,6 @@ case 512: launch_sort_small<512>(w, boxes, scores, counts, batch, nmax, st); bre
     }
     }
     DG_CHECK_LAUNCH("nms sort");
-    if (prune) {
-        hipLaunchKernelGGL(k_nms_xbucket, dim3((unsigned)batch), dim3(1024), 0, st, w.x1, w.x2, w.area, counts, nmax, w.Np,
-                           nms_prune_mode(), w.hdr, w.start, w.pos, w.lcnt);
-        hipLaunchKernelGGL(k_nms_xb_scatter, dim3((unsigned)dg_cdiv(w.Np, 256), (unsigned)batch), dim3(256), 0, st, w.x1, w.y1, w.x2, w.y2,
-                           w.area, w.pos, w.start, counts, nmax, w.hdr, w.Np, w.bbox, w.bar);
-        DG_CHECK_LAUNCH("k_nms_xbucket");
-    }
     return DG_OK;
 }
 
