@@ -452,15 +452,25 @@ __global__ __launch_bounds__(256) void k_nms_merge_rank(const float4 *__restrict
     int in[16];
 #pragma unroll
     for (int cc = 0; cc < 16; ++cc) in[cc] = 0;
+    // and the keys of the next block, in memory: a 4-ary search -- three pivots per chunk and step, 64 -> 16 -> 4 -> 1, the (at
+    // most 45) loads of a step in flight together: three dependent trips to the L2 instead of the six of a binary search (each
+    // of them 1.5-2 us with every wave of the launch waiting on one)
 #pragma unroll
-    for (int st = 32; st > 0; st >>= 1) {                         // and the keys of the next block: the chunks' loads of a step in flight together
-        u64 v[16];
+    for (int q = 16; q > 0; q >>= 2) {
+        u64 v[3][16];
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int cc = 0; cc < 16; ++cc)
+                v[t][cc] = (cc < nchunks && cc != c && blk[cc] < 64) ? kimg[(int64_t)cc * SORT_CHUNK + blk[cc] * 64 + in[cc] + (t + 1) * q - 1] : ~0ull;
 #pragma unroll
         for (int cc = 0; cc < 16; ++cc)
-            v[cc] = (cc < nchunks && cc != c && blk[cc] < 64) ? kimg[(int64_t)cc * SORT_CHUNK + blk[cc] * 64 + in[cc] + st - 1] : ~0ull;
+            if (cc < nchunks && cc != c && blk[cc] < 64) {
+                int cnt = 0;
 #pragma unroll
-        for (int cc = 0; cc < 16; ++cc)
-            if (cc < nchunks && cc != c && blk[cc] < 64 && (cc < c ? v[cc] <= K : v[cc] < K)) in[cc] += st;
+                for (int t = 0; t < 3; ++t) cnt += (cc < c ? v[t][cc] <= K : v[t][cc] < K) ? 1 : 0;    // sorted: the pivots before K are a prefix
+                in[cc] += cnt * q;
+            }
     }
 #pragma unroll
     for (int cc = 0; cc < 16; ++cc)
