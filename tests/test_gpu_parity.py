@@ -1150,6 +1150,28 @@ def test_kmeans_prepared_fit_vs_oracle(va, oracle, n, k, iters, monkeypatch):
         assert list(e._backend.history_host(3)) == hist[iters:iters + 3]
 
 
+@pytest.mark.parametrize("k", [3, 9, 15])
+def test_kmeans_boxes_outside_the_domain_vs_oracle(va, oracle, k, monkeypatch):
+    """Boxes the 1-IoU distance was not made for (a negative side, both negative, zero, far larger than 1, tiny): the specification
+    (oracle.c) is still an argmin over fp32 expressions, and both device loops follow it bit for bit -- the assignment pre-filter's
+    shortcut only holds where every key inter / (area + A_c) is at most 1/2 (a box (-0.3, 0.4) made keys beyond the pole of
+    x / (1 - x) and was assigned wrongly among 15 centroids until the filter refused such keys)."""
+    from vision_amd import cluster
+    n = 5000
+    wh = wl.anchor_wh(41, n)
+    odd = np.array([[3.0, 0.5], [0.0, 0.2], [1e-4, 1e-4], [-0.3, 0.4], [0.5, 7.0], [-0.2, -0.3], [0.4, -0.1], [-2.0, 0.05]], np.float32)
+    idx = np.random.default_rng(3).choice(n, 40, replace=False)
+    wh[idx] = odd[np.arange(40) % odd.shape[0]]
+    x = torch.from_numpy(wh).cuda()
+    cent, labels, n_iter, inertia = oracle.kmeans_fit(wh, k, 42, fixed_iters=12)
+    for cells in ("1", "0"):
+        monkeypatch.setenv("DG_KMEANS_CELLS", cells)
+        km = cluster.kmean(k, 42).fit(x, fixed_iters=12)
+        assert (km._backend.cells is not None) == (cells == "1")
+        assert np.array_equal(km.cluster_centers_.view(np.uint32), cent.view(np.uint32))
+        assert np.array_equal(km.labels_, labels) and abs(km.inertia_ - inertia) < 1e-9
+
+
 @pytest.mark.parametrize("max_iter", [5, 20, 40])
 def test_kmeans_prepared_fit_stopped_by_max_iter_vs_oracle(va, oracle, max_iter, monkeypatch):
     """A fit that runs until nothing changes issues its intermediate chunks over cells only (no pass over the boxes: dg_kmeans_iou_run_prepared

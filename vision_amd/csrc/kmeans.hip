@@ -68,11 +68,14 @@ __device__ __forceinline__ int km_assign(float w, float h, const float (&cw)[KMA
 // largest keys m1 >= m2.  When m1 - m2 > 256 ulp (>= 2^-16 relative) and m1 >= 2^-5 (so q >= x >= 2^-5), the exact
 // quotients differ by more than q * 2^-17 >= 2^-22, i.e. by several ulps of d = fl(1 - q): that cluster wins the exact
 // comparison strictly, whatever the index order, and only its d is evaluated exactly.  Anything else (near ties, tiny
-// overlaps, NaN/inf/negative keys, which the unsigned max drags into m1) takes km_assign.  Callers bound |w|+|h| < 2^19
+// overlaps, NaN/inf/negative keys, which the unsigned max drags into m1) takes km_assign.  So does ANY key above 1/2: with
+// positive boxes and centroids inter <= min(area, A_c) <= (area + A_c) / 2, so x <= 1/2 always; a box with a negative side
+// can make area + A_c negative and x anything -- x / (1 - x) has a pole at 1, beyond which a larger key is a SMALLER
+// quotient (found by tools/stress_kmeans.py: a box (-0.3, 0.4) among 15 centroids went to the wrong one; the bound was +inf).  Callers bound |w|+|h| < 2^19
 // and centroid areas < 2^60 so that rcp(area + A_c) stays a normal number.
 #define KM_GAP_MIN 256u
 #define KM_KEY_LO 0x3D000000u           /* 2^-5 */
-#define KM_KEY_HI 0x7F800000u           /* +inf: NaN and sign-bit keys compare above it */
+#define KM_KEY_HI 0x3F000040u           /* just above 1/2: see below; NaN, inf and sign-bit keys compare above it too */
 __device__ __forceinline__ unsigned umed3(unsigned a, unsigned b, unsigned c)
 {
     unsigned r;
