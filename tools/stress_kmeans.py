@@ -24,7 +24,7 @@ def boxes(kind, seed, n):
         return base[r.integers(0, base.shape[0], n)]
     wh = wl.anchor_wh(seed % 97, n)                      # with boxes outside the grid: the catch-all cells
     idx = r.integers(0, n, max(1, n // 500))
-    wh[idx] = r.choice(np.array([[3.0, 0.5], [0.0, 0.2], [1e-4, 1e-4], [-0.3, 0.4], [0.5, 7.0]], np.float32), idx.shape[0])
+    wh[idx] = r.choice(np.array([[3.0, 0.5], [0.0, 0.2], [1e-4, 1e-4], [-0.3, 0.4], [0.5, 7.0], [-0.2, -0.3], [0.4, -0.1], [1e6, 0.3], [6e5, 7e5], [2e-30, 0.5], [-1e6, 2.0]], np.float32), idx.shape[0])
     return wh
 
 def fit(x, k, cells, **kw):
