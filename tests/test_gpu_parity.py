@@ -674,17 +674,22 @@ def test_roipool_config1_vs_oracle(va, oracle):
     np.testing.assert_allclose(gin, wgin, rtol=1e-4, atol=1e-4)     # fp32 sums of ~50 terms in a different order
 
 
-@pytest.mark.parametrize("with_nan", [False, True])
+@pytest.mark.parametrize("with_nan", [False, True, "inf", "inf+nan"])
 def test_roipool_every_crop_width_with_ties(va, oracle, with_nan):
     """Every crop width 1..50 (the width-specialised, the generic staged and the direct code paths) at assorted heights,
     on a map quantised to a few levels so that almost every bin has tied maxima (first one must win, as in ATen),
-    with both signs of zero, and optionally NaNs (a NaN always wins)."""
+    with both signs of zero, and optionally NaNs (a NaN always wins) and infinities (a bin of -inf alone keeps its first
+    cell: the running maximum starts at -inf and only a strictly larger value replaces it)."""
     from vision_amd import ops
     rng = np.random.default_rng(17)
     B, C, H, W = 2, 128, 38, 50
     levels = np.array([-2.0, -1.0, -0.0, 0.0, 0.5, 1.0], np.float32)
+    if isinstance(with_nan, str):
+        levels = np.array([-np.inf, -np.inf, -np.inf, -1.0, -0.0, 0.0, np.inf], np.float32)
     img = levels[rng.integers(0, len(levels), (B, C, H, W))]
-    if with_nan:
+    if isinstance(with_nan, str):
+        img[:, :, :, 30:] = np.where(rng.random((B, C, H, W - 30)) < 0.9, -np.inf, img[:, :, :, 30:])   # whole bins of -inf
+    if with_nan is True or with_nan == "inf+nan":
         img[rng.random(img.shape) < 0.002] = np.nan
     wins = []
     for lw in range(1, W + 1):
