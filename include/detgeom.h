@@ -140,10 +140,12 @@ int dg_yolo2_decode_anchor_f32(const float *pred, int64_t G, int64_t A, int64_t 
 
 /* ---------------------------------------------------------------- RoI pooling
  * R1 slowroipool.foward(img,roi_ary,roi_idx): rcnn/fast_rcnn.py:351-377.
- * dg_roi_windows does :366-369 (+ python slice clamping): rois (n,4) float64 normalised xyxy,
- * roi_idx (n) int64 -> win (n,5) int32 = {x1,y1,x2,y2,image}.  *status (device int32, zeroed by the
- * caller) is OR-ed with 1 if some crop is empty (the reference raises RuntimeError there) and with 2 if
- * an image index is out of range. */
+ * dg_roi_windows does :366-369 and the slice normalisation of the crop at :374: rois (n,4) float64 normalised xyxy,
+ * roi_idx (n) int64 -> win (n,5) int32 = {x1,y1,x2,y2,image}.  A negative bound counts from the end (start AND stop, as
+ * python slices do), bounds are clamped to [0, size]; a NaN, an infinity or a product outside int64 gives bound 0 (numpy's
+ * astype(int) makes INT64_MIN of them on x86-64); a negative image index counts from the last image.  *status (device
+ * int32, zeroed by the caller) is OR-ed with 1 if some crop is empty (the reference raises RuntimeError there) and with 2
+ * if an image index is out of range (IndexError there). */
 int dg_roi_windows(const double *rois, const int64_t *roi_idx, int64_t n, int64_t B, int64_t H, int64_t W,
                    int32_t *win, int32_t *status, dg_stream_t s);
 /* (B,C,H,W) -> (B,H,W,C) staging copy used by the forward kernel (lanes = channels).  nan_flag (device

@@ -214,18 +214,26 @@ int64_t orc_yolo1_decode(const float *output, const float *target, int64_t C,
 static inline int bin_start(int i, int L, int P) { return (i * L) / P; }
 static inline int bin_end(int i, int L, int P) { return ((i + 1) * L + P - 1) / P; }
 
+/* One bound of a python slice, as rcnn/fast_rcnn.py:366-374 makes it: np.floor / np.ceil of coordinate x size, `.astype(int)`
+ * (int64: a NaN, an infinity or a value outside int64 becomes INT64_MIN on x86-64, with a warning), then used as a slice
+ * bound on a dimension of `size` cells: a negative bound counts from the end, and the result is clamped to [0, size].  BOTH
+ * bounds wrap (a stop of -1 is the last column), not only the start.  No conversion of an out-of-range double (undefined in
+ * C): everything outside [-size, size] is decided in double. */
+static int py_slice_bound(double v, int size)
+{
+    if (!(v >= -9223372036854775808.0 && v < 9223372036854775808.0)) return 0;   /* INT64_MIN + size < 0 -> 0 */
+    if (v < -(double)size) return 0;
+    if (v > (double)size) return size;
+    int i = (int)v;                                 /* |v| <= size: exact (v is an integer: floor / ceil made it) */
+    return i < 0 ? i + size : i;
+}
 int orc_roi_window(const double *roi, int H, int W, int *x1, int *y1, int *x2, int *y2)
 {
-    *x1 = (int)floor(roi[0] * (double)W);
-    *x2 = (int)ceil(roi[2] * (double)W);
-    *y1 = (int)floor(roi[1] * (double)H);
-    *y2 = (int)ceil(roi[3] * (double)H);
-    /* python slicing clamps; an empty crop makes torch raise */
-    if (*x1 < 0) *x1 = (*x1 + W < 0) ? 0 : *x1 + W;   /* negative python index wraps */
-    if (*y1 < 0) *y1 = (*y1 + H < 0) ? 0 : *y1 + H;
-    if (*x2 > W) *x2 = W;
-    if (*y2 > H) *y2 = H;
-    if (*x2 <= *x1 || *y2 <= *y1) return ORC_EEMPTYROI;
+    *x1 = py_slice_bound(floor(roi[0] * (double)W), W);         /* :366 */
+    *x2 = py_slice_bound(ceil(roi[2] * (double)W), W);          /* :367 */
+    *y1 = py_slice_bound(floor(roi[1] * (double)H), H);         /* :368 */
+    *y2 = py_slice_bound(ceil(roi[3] * (double)H), H);          /* :369 */
+    if (*x2 <= *x1 || *y2 <= *y1) return ORC_EEMPTYROI;         /* an empty crop makes the adaptive pool raise */
     return ORC_OK;
 }
 
@@ -239,7 +247,8 @@ int orc_roipool_fwd2_f32(const float *img, int64_t B, int64_t C, int H, int W,
         int st = orc_roi_window(rois + 4 * r, H, W, &x1, &y1, &x2, &y2);
         if (st) return st;
         int64_t b = roi_idx[r];
-        if (b < 0 || b >= B) return ORC_EINVAL;
+        if (b < 0) b += B;                          /* :374 img[roi_idx[i], ...]: a negative index counts from the end */
+        if (b < 0 || b >= B) return ORC_EINVAL;     /* (torch raises IndexError) */
         int Lh = y2 - y1, Lw = x2 - x1;
         for (int64_t c = 0; c < C; ++c) {
             const float *plane = img + (b * C + c) * (int64_t)H * W;
@@ -284,12 +293,14 @@ int orc_roipool_bwd2_f32(const float *grad_out, const int32_t *argmax, int64_t B
                          const double *rois, const int64_t *roi_idx, int64_t n, int PH, int PW, int mode,
                          float *grad_in)
 {
-    (void)B;                                     /* the caller sized (and zeroed) grad_in; roi_idx is trusted as in the reference */
+    /* the caller sized (and zeroed) grad_in */
     for (int64_t r = 0; r < n; ++r) {
         int x1, y1, x2, y2;
         int st = orc_roi_window(rois + 4 * r, H, W, &x1, &y1, &x2, &y2);
         if (st) return st;
         int64_t b = roi_idx[r];
+        if (b < 0) b += B;                          /* as the forward */
+        if (b < 0 || b >= B) return ORC_EINVAL;
         int Lh = y2 - y1, Lw = x2 - x1;
         for (int64_t c = 0; c < C; ++c) {
             float *plane = grad_in + (b * C + c) * (int64_t)H * W;

@@ -674,6 +674,38 @@ def test_roipool_config1_vs_oracle(va, oracle):
     np.testing.assert_allclose(gin, wgin, rtol=1e-4, atol=1e-4)     # fp32 sums of ~50 terms in a different order
 
 
+def test_roi_windows_out_of_domain_vs_oracle(va, oracle):
+    """dg_roi_windows on RoIs the reference never meant to see -- far outside [0, 1], reversed, on cell boundaries, a hair below
+    zero, negative stops (python wraps them too), NaN, infinities, negative image indices (counted from the last image) --
+    against the oracle's window, which tests/test_oracle_golden.py pins to numpy's conversion and python's slice normalisation."""
+    import ctypes as C
+    from vision_amd import ops
+    lib = oracle.lib()
+    rng = np.random.default_rng(8)
+    special = np.array([-1e-18, 1e-18, 1 - 1e-16, 1 + 1e-15, 0.0, 1.0, -1.0, 2.0, 1e12, -1e12, 1e300, -1e300, np.nan, np.inf, -np.inf, -0.4, -0.02])
+    for H, W in ((38, 50), (1, 1), (7, 300), (233, 3)):
+        n = 3000
+        kind = rng.integers(0, 4, (n, 4))
+        grid = np.stack([rng.integers(-2, W + 3, n) / W, rng.integers(-2, H + 3, n) / H, rng.integers(-2, W + 3, n) / W, rng.integers(-2, H + 3, n) / H], 1)
+        rois = np.where(kind == 0, rng.uniform(-1.5, 2.5, (n, 4)), np.where(kind == 1, grid, np.where(kind == 2, rng.uniform(0, 1, (n, 4)),
+                        special[rng.integers(0, len(special), (n, 4))])))
+        rois = np.ascontiguousarray(rois, np.float64)
+        idx = rng.integers(-4, 4, n).astype(np.int64)
+        win, status = ops.roi_windows(rois, idx, 4, H, W, torch.device("cuda", 0))
+        win = win.cpu().numpy()
+        any_empty = False
+        for r in range(n):
+            a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            rc = lib.orc_roi_window(rois[r].ctypes.data_as(C.POINTER(C.c_double)), C.c_int(H), C.c_int(W), C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+            if rc != 0:
+                any_empty = True
+                continue
+            assert tuple(int(v) for v in win[r]) == (a.value, b.value, c.value, d.value, int(idx[r]) % 4), (H, W, rois[r])
+        assert int(status.item()) == (1 if any_empty else 0)
+    _, status = ops.roi_windows(np.array([[0.1, 0.1, 0.5, 0.5]]), np.array([-5], np.int64), 4, 38, 50, torch.device("cuda", 0))
+    assert int(status.item()) == 2                                # an image index python would refuse as well
+
+
 @pytest.mark.parametrize("with_nan", [False, True, "inf", "inf+nan"])
 def test_roipool_every_crop_width_with_ties(va, oracle, with_nan):
     """Every crop width 1..50 (the width-specialised, the generic staged and the direct code paths) at assorted heights,

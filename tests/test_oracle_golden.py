@@ -102,6 +102,43 @@ def test_roipool(golden, oracle):
         oracle.roipool_fwd(g["img"], g["empty_rois"], g["idx"][:2])
 
 
+def test_roi_window_is_python_slicing(oracle):
+    """rcnn/fast_rcnn.py:366-374: `np.floor(x1 * w).astype(int)` ... then `img[roi_idx[i], :, y1:y2, x1:x2]`.  The oracle's window
+    (orc_roi_window) against numpy's own conversion and python's own slice normalisation (slice.indices) on RoIs far outside
+    [0, 1], reversed, on cell boundaries, a hair below zero (start -1 = the last column), with a NEGATIVE STOP (wraps too),
+    NaN and infinities (INT64_MIN from astype(int) on this platform: bound 0)."""
+    import ctypes as C
+    import warnings
+    lib = oracle.lib()
+    rng = np.random.default_rng(12)
+    special = np.array([-1e-18, 1e-18, 1 - 1e-16, 1 + 1e-15, 0.0, 1.0, -1.0, 2.0, 1e12, -1e12, 1e300, -1e300, np.nan, np.inf, -np.inf, -0.4, -0.02])
+    checked = nonempty = 0
+    for _ in range(60):
+        H, W = int(rng.integers(1, 120)), int(rng.integers(1, 120))
+        n = 200
+        kind = rng.integers(0, 4, (n, 4))
+        grid = np.stack([rng.integers(-2, W + 3, n) / W, rng.integers(-2, H + 3, n) / H, rng.integers(-2, W + 3, n) / W, rng.integers(-2, H + 3, n) / H], 1)
+        rois = np.where(kind == 0, rng.uniform(-1.5, 2.5, (n, 4)), np.where(kind == 1, grid, np.where(kind == 2, rng.uniform(0, 1, (n, 4)),
+                        special[rng.integers(0, len(special), (n, 4))])))
+        rois = np.ascontiguousarray(rois, np.float64)
+        with warnings.catch_warnings(), np.errstate(invalid="ignore"):
+            warnings.simplefilter("ignore")
+            x1 = np.floor(rois[:, 0] * W).astype(int); x2 = np.ceil(rois[:, 2] * W).astype(int)      # the reference's lines
+            y1 = np.floor(rois[:, 1] * H).astype(int); y2 = np.ceil(rois[:, 3] * H).astype(int)
+        for r in range(n):
+            xs, xe, _ = slice(int(x1[r]), int(x2[r])).indices(W)
+            ys, ye, _ = slice(int(y1[r]), int(y2[r])).indices(H)
+            a, b, c, d = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+            rc = lib.orc_roi_window(rois[r].ctypes.data_as(C.POINTER(C.c_double)), C.c_int(H), C.c_int(W), C.byref(a), C.byref(b), C.byref(c), C.byref(d))
+            empty = xe <= xs or ye <= ys
+            assert (rc != 0) == empty, (H, W, rois[r])
+            if not empty:
+                assert (a.value, b.value, c.value, d.value) == (xs, ys, xe, ye), (H, W, rois[r])
+                nonempty += 1
+            checked += 1
+    assert checked == 12000 and nonempty > 1500
+
+
 def test_roipool_other_output_sizes(golden, oracle):
     """slowroipool(output_size) with sizes other than (7,7) -- the reference's class as written (avg) and with
     AdaptiveMaxPool2d substituted, values, argmax and autograd gradients generated from the reference."""

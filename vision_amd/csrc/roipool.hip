@@ -38,15 +38,21 @@ __global__ __launch_bounds__(256) void k_roi_windows(const double *__restrict__ 
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const double *r = rois + 4 * i;
-    int x1 = (int)floor(r[0] * (double)W), x2 = (int)ceil(r[2] * (double)W);
-    int y1 = (int)floor(r[1] * (double)H), y2 = (int)ceil(r[3] * (double)H);
-    if (x1 < 0) x1 = (x1 + W < 0) ? 0 : x1 + W;     // python: negative start wraps, then clamps
-    if (y1 < 0) y1 = (y1 + H < 0) ? 0 : y1 + H;
-    if (x2 > W) x2 = W;
-    if (y2 > H) y2 = H;
+    // :366-369 then the crop `img[idx, :, y1:y2, x1:x2]` (:374): python slice bounds -- BOTH wrap when negative, both clamp to
+    // [0, size]; .astype(int) of a NaN / infinity / value outside int64 is INT64_MIN on x86-64, which the slice clamps to 0
+    auto bound = [](double v, int size) -> int {
+        if (!(v >= -9223372036854775808.0 && v < 9223372036854775808.0)) return 0;
+        if (v < -(double)size) return 0;
+        if (v > (double)size) return size;
+        const int q = (int)v;
+        return q < 0 ? q + size : q;
+    };
+    int x1 = bound(floor(r[0] * (double)W), W), x2 = bound(ceil(r[2] * (double)W), W);
+    int y1 = bound(floor(r[1] * (double)H), H), y2 = bound(ceil(r[3] * (double)H), H);
     int64_t b = roi_idx[i];
     int st = 0;
     if (x2 <= x1 || y2 <= y1) { st |= 1; x1 = 0; y1 = 0; x2 = 1; y2 = 1; }   // keep later kernels in bounds
+    if (b < 0) b += B;                                  // `img[roi_idx[i]]`: a negative index counts from the last image
     if (b < 0 || b >= B) { st |= 2; b = 0; }
     if (st) atomicOr(status, st);
     int32_t *w = win + 5 * i;
