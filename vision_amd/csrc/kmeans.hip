@@ -157,7 +157,9 @@ __device__ __forceinline__ void km_one(float w, float h, const float (&cw)[KMAX]
 // (the previous iteration's buffer, all-reduced when sharded; NULL = plain step with the centroids as given) and zeroes
 // part_zero (the buffer the NEXT launch adds into; NULL = nobody needs it).  With three buffers in rotation no zeroing
 // ever races: the buffer zeroed by launch t was last read by launch t-1.
+#ifndef KM_REPL
 #define KM_REPL 8
+#endif
 __host__ __device__ static inline int km_stride(int k) { return ((3 * k + 2) + 15) & ~15; }
 __device__ __forceinline__ float km_centroid(long long sum, long long cnt)      // as k_kmeans_finish / orc_kmeans_update
 {
