@@ -1187,6 +1187,30 @@ def test_kmeans_prepared_fit_vs_oracle(va, oracle, n, k, iters, monkeypatch):
         assert list(e._backend.history_host(3)) == hist[iters:iters + 3]
 
 
+@pytest.mark.parametrize("n,k,iters", [(300001, 5, 12), (250000, 9, None), (5000, 16, 9), (1200000, 5, 20)])
+def test_kmeans_persistent_kernel_vs_oracle(va, oracle, n, k, iters, monkeypatch):
+    """DG_KMEANS_PERSIST=1: all cell iterations of a chunk in one launch with a grid barrier per iteration (k_kc_persist; opt-in,
+    measured slower than a launch per iteration): same centroids, labels, n_iter_, inertia and changed counts as the oracle, for a
+    fixed number of iterations and for a fit that runs until nothing changes (whose chunks run over cells only until the last)."""
+    from vision_amd import cluster
+    wh = wl.anchor_wh(n % 89, n)
+    if n == 5000:
+        wh[::250] = [3.0, 0.5]; wh[3] = [-0.3, 0.4]; wh[9] = [0.0, 0.2]
+    x = torch.from_numpy(wh).cuda()
+    monkeypatch.setenv("DG_KMEANS_CELLS", "1")
+    monkeypatch.setenv("DG_KMEANS_PERSIST", "1")
+    km = cluster.kmean(k, 42).fit(x, fixed_iters=iters)
+    assert km._backend.cells is not None
+    cent, labels, n_iter, inertia = oracle.kmeans_fit(wh, k, 42, fixed_iters=iters) if iters else oracle.kmeans_fit(wh, k, 42)
+    assert np.array_equal(km.cluster_centers_.view(np.uint32), cent.view(np.uint32))
+    assert np.array_equal(km.labels_, labels) and km.n_iter_ == n_iter and abs(km.inertia_ - inertia) < 1e-9
+    if iters:
+        lab = np.full(n, 255, np.uint8); ce = oracle.kmeans_init(wh, k, 42); hist = []
+        for _ in range(iters):
+            acc = oracle.kmeans_step(wh, ce, lab); hist.append(int(acc[3 * k])); ce = oracle.kmeans_update(acc, ce)
+        assert list(km._backend.history_host(iters)) == hist
+
+
 @pytest.mark.parametrize("k", [3, 9, 15])
 def test_kmeans_boxes_outside_the_domain_vs_oracle(va, oracle, k, monkeypatch):
     """Boxes the 1-IoU distance was not made for (a negative side, both negative, zero, far larger than 1, tiny): the specification
