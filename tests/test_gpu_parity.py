@@ -88,6 +88,27 @@ def test_nms_large_vs_oracle(va, oracle, n, dense, thr):
     assert np.array_equal(keep.cpu().numpy(), oracle.nms(b, s, thr)), (n, dense, thr)
 
 
+@pytest.mark.parametrize("switch", [("DG_NMS_FP_SYNC", "1"), ("DG_NMS_BAND_PARTS", "1"), ("DG_NMS_BAND_PARTS", "5")])
+def test_nms_pruned_path_switches_vs_oracle(va, oracle, switch, monkeypatch):
+    """The pruned path's opt-in variants: the fixed point with a grid barrier per round (k_nms_resolve_mc, DG_NMS_FP_SYNC=1; the
+    default is the free-running k_nms_resolve_async) and other splits of a row tile's band over workgroups (DG_NMS_BAND_PARTS);
+    ragged batches of sparse and dense sets, both quirk settings, against the oracle."""
+    from vision_amd import ops
+    monkeypatch.setenv(*switch)
+    for n, dense, thr in ((5000, False, 0.5), (20000, True, 0.6), (9000, True, 0.3), (33000, False, 0.4)):
+        B = 2
+        counts = np.array([n, n - 1234], np.int32)
+        boxes = np.zeros((B, n, 4), np.float32); scores = np.zeros((B, n), np.float32)
+        for i in range(B):
+            boxes[i], scores[i] = wl.stress_boxes(77 + n + i, n, dense=dense)
+        for quirk in (True, False):
+            keep, cnt = ops.nms_batched(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), torch.from_numpy(counts), thr, quirk)
+            keep, cnt = keep.cpu().numpy(), cnt.cpu().numpy()
+            for i in range(B):
+                want = oracle.nms(boxes[i, :counts[i]], scores[i, :counts[i]], thr, quirk)
+                assert cnt[i] == len(want) and np.array_equal(keep[i, :cnt[i]], want), (switch, n, thr, quirk, i)
+
+
 @pytest.mark.parametrize("dense", [False, True])
 def test_nms_band_reduce_forced_vs_oracle(va, oracle, dense, monkeypatch):
     """k_nms_reduce_band (the reduce of images whose compact mask form overflows) on every kind of input: with
