@@ -88,6 +88,16 @@ def test_nms_large_vs_oracle(va, oracle, n, dense, thr):
     assert np.array_equal(keep.cpu().numpy(), oracle.nms(b, s, thr)), (n, dense, thr)
 
 
+@pytest.mark.parametrize("n,dense,thr", [(70001, False, 0.5), (100000, True, 0.6)])
+def test_nms_beyond_65536_boxes_vs_oracle(va, oracle, n, dense, thr):
+    """Images of more than 65536 boxes: the global bitonic network, the gather, the dense mask and the serial chain over more than
+    1024 row blocks (the pruned path and the chunk sort end at 65536)."""
+    from vision_amd import ops
+    b, s = wl.stress_boxes(5, n, dense=dense)
+    keep, kc = ops.nms_batched(torch.from_numpy(b).cuda()[None], torch.from_numpy(s).cuda()[None], None, thr, True)
+    assert np.array_equal(keep[0, :int(kc[0])].cpu().numpy(), oracle.nms(b, s, thr, True))
+
+
 @pytest.mark.parametrize("switch", [("DG_NMS_FP_SYNC", "1"), ("DG_NMS_BAND_PARTS", "1"), ("DG_NMS_BAND_PARTS", "5")])
 def test_nms_pruned_path_switches_vs_oracle(va, oracle, switch, monkeypatch):
     """The pruned path's opt-in variants: the fixed point with a grid barrier per round (k_nms_resolve_mc, DG_NMS_FP_SYNC=1; the
