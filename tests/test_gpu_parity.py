@@ -88,6 +88,55 @@ def test_nms_large_vs_oracle(va, oracle, n, dense, thr):
     assert np.array_equal(keep.cpu().numpy(), oracle.nms(b, s, thr)), (n, dense, thr)
 
 
+def test_abi_entry_points_the_wrappers_do_not_use(va, oracle):
+    """Entry points of include/detgeom.h that vision_amd's own wrappers route around (tools/abi_coverage.py lists what a test run
+    reached): the NMS phases called one after the other (what bench.py times; the same keep list as the one-call entry point and as
+    the oracle, on the pruned path, the dense path and a small image), dg_roipool_fwd_f32 / dg_roipool_bwd_f32 (the 7 x 7, int32-argmax
+    entry points; the wrappers go through the *_any_* ones) against the oracle, dg_version, dg_comm_rank / dg_comm_size."""
+    from vision_amd import ops, _abi, cluster
+    lib = _abi.load()
+    dev = torch.device("cuda", 0)
+    sp = _abi.stream_ptr(dev)
+    assert b"gfx950" in lib.dg_version()
+    for n, dense, thr in ((20000, False, 0.5), (9000, True, 0.3), (2000, False, 0.7), (300, True, 0.5)):
+        b, s = wl.stress_boxes(3 + n, n, dense=dense)
+        bt, st = torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()
+        ws, nb = ops.nms_workspace(dev, 1, n)
+        keep = torch.full((1, n), -1, dtype=torch.int64, device=dev); kc = torch.zeros((1,), dtype=torch.int32, device=dev)
+        _abi.check(lib.dg_nms_phase_sort(_abi.ptr(bt), _abi.ptr(st), None, 1, n, _abi.ptr(ws), nb, sp))
+        for _ in range(2):                                       # the later phases may be run again on a sorted workspace
+            _abi.check(lib.dg_nms_phase_mask(None, 1, n, thr, _abi.ptr(ws), nb, sp))
+            _abi.check(lib.dg_nms_phase_reduce(None, 1, n, 1, _abi.ptr(keep), _abi.ptr(kc), _abi.ptr(ws), nb, sp))
+        want = oracle.nms(b, s, thr, True)
+        assert int(kc[0]) == len(want) and np.array_equal(keep[0, :len(want)].cpu().numpy(), want), (n, dense, thr)
+    # 7 x 7 max pooling with int32 argmax through the dedicated entry points
+    rng = np.random.default_rng(4)
+    B, Cn, H, W, n = 2, 128, 38, 50, 300
+    img = rng.standard_normal((B, Cn, H, W), dtype=np.float32)
+    rois = np.concatenate([wl.frcnn_rois(i, n // B) for i in range(B)])
+    idx = np.repeat(np.arange(B), n // B).astype(np.int64)
+    x = torch.from_numpy(img).cuda()
+    win, status = ops.roi_windows(rois, idx, B, H, W, dev)
+    nhwc, nanf = ops.to_nhwc(x)
+    out = torch.empty((n, Cn, 7, 7), dtype=torch.float32, device=dev); arg = torch.empty((n, Cn, 7, 7), dtype=torch.int32, device=dev)
+    _abi.check(lib.dg_roipool_fwd_f32(_abi.ptr(nhwc), B, Cn, H, W, _abi.ptr(win), n, 7, _abi.POOL_MAX, _abi.ptr(nanf), _abi.ptr(out), _abi.ptr(arg), sp))
+    want, warg = oracle.roipool_fwd(img, rois, idx, 7, "max")
+    assert np.array_equal(out.cpu().numpy(), want) and np.array_equal(arg.cpu().numpy(), warg)
+    gout = torch.from_numpy(rng.standard_normal((n, Cn, 7, 7), dtype=np.float32)).cuda()
+    gin = torch.full((B, Cn, H, W), 7.0, dtype=torch.float32, device=dev)          # overwritten, not accumulated
+    nbw = lib.dg_roipool_bwd_workspace_bytes(B, n)
+    wsb = ops.workspace(dev, nbw)
+    _abi.check(lib.dg_roipool_bwd_f32(_abi.ptr(gout), _abi.ptr(arg), _abi.ptr(win), n, B, Cn, H, W, 7, _abi.POOL_MAX, _abi.ptr(gin), _abi.ptr(wsb), nbw, sp))
+    wgin = oracle.roipool_bwd(gout.cpu().numpy(), warg, img.shape, rois, idx, 7, "max")
+    np.testing.assert_allclose(gin.cpu().numpy(), wgin, rtol=1e-4, atol=1e-4)          # fp32 sums in a different order
+    # a communicator's rank and size (a single-rank RCCL group, made without a process group)
+    comm = cluster.DgComm.create(None, dev)
+    try:
+        assert lib.dg_comm_rank(comm.handle) == 0 and lib.dg_comm_size(comm.handle) == 1
+    finally:
+        comm.close()
+
+
 @pytest.mark.parametrize("n,dense,thr", [(70001, False, 0.5), (100000, True, 0.6)])
 def test_nms_beyond_65536_boxes_vs_oracle(va, oracle, n, dense, thr):
     """Images of more than 65536 boxes: the global bitonic network, the gather, the dense mask and the serial chain over more than
