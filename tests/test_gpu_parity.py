@@ -88,6 +88,33 @@ def test_nms_large_vs_oracle(va, oracle, n, dense, thr):
     assert np.array_equal(keep.cpu().numpy(), oracle.nms(b, s, thr)), (n, dense, thr)
 
 
+@pytest.mark.parametrize("B,C,per,a16", [(16, 256, 40, True), (64, 72, 12, False), (64, 72, 12, True), (1, 6, 300, False), (1, 6, 300, True),
+                                         (1, 64, 300, True)])
+def test_roipool_backward_slice_shapes_vs_oracle(va, oracle, B, C, per, a16):
+    """The max backward's instantiations that the other tests' shapes do not reach (a kernel trace of the test run against the
+    compiled instantiations found them): 16-channel slices with a uint16 argmax (B * C / 16 >= 256), 8-channel slices (a channel
+    count that is a multiple of 8 but not of 16, B * C / 8 >= 512) with either argmax width, and the single-image kernel that takes
+    the RoIs in order itself on a channel count that rules out the 16-byte path, and with the uint16 argmax."""
+    from vision_amd import ops
+    rng = np.random.default_rng(B * 1000 + C)
+    H, W = 38, 50
+    n = B * per
+    img = rng.standard_normal((B, C, H, W), dtype=np.float32)
+    rois = np.concatenate([wl.frcnn_rois(100 + i, per) for i in range(B)])
+    idx = np.repeat(np.arange(B), per).astype(np.int64)
+    x = torch.from_numpy(img).cuda()
+    win, status = ops.roi_windows(rois, idx, B, H, W, x.device)
+    assert int(status.item()) == 0
+    out, arg = ops.roipool_forward(x, win, "max", argmax_dtype=torch.int16 if a16 else torch.int32)
+    want, warg = oracle.roipool_fwd(img, rois, idx, 7, "max")
+    assert np.array_equal(out.cpu().numpy(), want)
+    assert np.array_equal((ops.argmax_i32(arg) if a16 else arg).cpu().numpy(), warg)
+    gout = rng.standard_normal((n, C, 7, 7), dtype=np.float32)
+    gin = ops.roipool_backward(torch.from_numpy(gout).cuda(), arg, win, img.shape, "max")
+    wgin = oracle.roipool_bwd(gout, warg, img.shape, rois, idx, 7, "max")
+    np.testing.assert_allclose(gin.cpu().numpy(), wgin, rtol=1e-4, atol=1e-4)          # fp32 sums in a different order
+
+
 def test_abi_entry_points_the_wrappers_do_not_use(va, oracle):
     """Entry points of include/detgeom.h that vision_amd's own wrappers route around (tools/abi_coverage.py lists what a test run
     reached): the NMS phases called one after the other (what bench.py times; the same keep list as the one-call entry point and as
@@ -137,10 +164,11 @@ def test_abi_entry_points_the_wrappers_do_not_use(va, oracle):
         comm.close()
 
 
-@pytest.mark.parametrize("n,dense,thr", [(70001, False, 0.5), (100000, True, 0.6)])
+@pytest.mark.parametrize("n,dense,thr", [(70001, False, 0.5), (100000, True, 0.6), (270000, True, 0.3)])
 def test_nms_beyond_65536_boxes_vs_oracle(va, oracle, n, dense, thr):
     """Images of more than 65536 boxes: the global bitonic network, the gather, the dense mask and the serial chain over more than
-    1024 row blocks (the pruned path and the chunk sort end at 65536)."""
+    1024 row blocks (the pruned path and the chunk sort end at 65536); beyond 262144 boxes the chain's widest instantiation
+    (sixteen words of `removed` per thread, an 8.6 GB mask)."""
     from vision_amd import ops
     b, s = wl.stress_boxes(5, n, dense=dense)
     keep, kc = ops.nms_batched(torch.from_numpy(b).cuda()[None], torch.from_numpy(s).cuda()[None], None, thr, True)
@@ -1219,7 +1247,7 @@ def test_kmeans_fixed_iterations_vs_oracle(va, oracle, iters):
     assert km.n_iter_ == iters and abs(km.inertia_ - inertia) < 1e-9
 
 
-@pytest.mark.parametrize("n,k,iters", [(300001, 5, None), (250000, 9, 12), (500000, 3, 7), (400000, 16, 5), (1000, 5, None)])
+@pytest.mark.parametrize("n,k,iters", [(300001, 5, None), (250000, 9, 12), (500000, 3, 7), (400000, 16, 5), (1000, 5, None), (260000, 7, 9)])
 def test_kmeans_prepared_fit_vs_oracle(va, oracle, n, k, iters, monkeypatch):
     """The prepared fit (dg_kmeans_prepare + dg_kmeans_iou_run_prepared: boxes grouped by (w, h) cell once, whole pieces of a
     cell labelled at once where the bounds on the IoUs leave no doubt, the rest box by box): centroids, labels, n_iter_ and
@@ -1267,7 +1295,7 @@ def test_kmeans_prepared_fit_vs_oracle(va, oracle, n, k, iters, monkeypatch):
         assert list(e._backend.history_host(3)) == hist[iters:iters + 3]
 
 
-@pytest.mark.parametrize("n,k,iters", [(300001, 5, 12), (250000, 9, None), (5000, 16, 9), (1200000, 5, 20)])
+@pytest.mark.parametrize("n,k,iters", [(300001, 5, 12), (250000, 9, None), (5000, 16, 9), (1200000, 5, 20), (220000, 3, 8), (210000, 7, 8)])
 def test_kmeans_persistent_kernel_vs_oracle(va, oracle, n, k, iters, monkeypatch):
     """DG_KMEANS_PERSIST=1: all cell iterations of a chunk in one launch with a grid barrier per iteration (k_kc_persist; opt-in,
     measured slower than a launch per iteration): same centroids, labels, n_iter_, inertia and changed counts as the oracle, for a
