@@ -82,7 +82,9 @@ __global__ __launch_bounds__(256) void k_roipool_bwd_generic_max(const float *__
         const int c = (int)(rc - roi * C);
         const int b = win[5 * roi + 4];
         const int64_t a = IDX16 ? (int64_t)reinterpret_cast<const unsigned short *>(argmax)[e] : (int64_t)reinterpret_cast<const int32_t *>(argmax)[e];
-        atomicAdd(&grad_in[((int64_t)b * C + c) * HW + a], grad_out[e]);
+        // (an index outside the plane cannot come from the forward; one handed in from elsewhere must not become a write outside
+        //  grad_in -- the tuned kernel's planes live in LDS, where the hardware drops an out-of-range access)
+        if ((uint64_t)a < (uint64_t)HW) atomicAdd(&grad_in[((int64_t)b * C + c) * HW + a], grad_out[e]);
     }
 }
 
