@@ -56,7 +56,7 @@ int dg_iou_rois_vs_gt_f64(const double *rois, const double *grt, int64_t n, doub
 /* ---------------------------------------------------------------- NMS
  * N1 nms(out_box,out_score,threshold): yolo/yolo_v1/yolo.py:188-203, batched over images.
  * boxes: (batch,nmax,4) fp32 xyxy; scores: (batch,nmax); counts: (batch) int32 candidates per image
- * or NULL (= nmax each).  keep: (batch,nmax) int64 indices into the image's unsorted input in
+ * or NULL (= nmax each); a count is held to [0, nmax] on the device (it never becomes a read outside the image's boxes).  keep: (batch,nmax) int64 indices into the image's unsorted input in
  * descending-score order (ties: lower index first); keep_count: (batch) int32.
  * quirk_drop_last=1 reproduces the reference's `while numel()>1` (the candidate left alone is dropped).
  * The compare is `iou < (float)threshold` exactly as torch evaluates :201. */

@@ -164,6 +164,23 @@ def test_abi_entry_points_the_wrappers_do_not_use(va, oracle):
         comm.close()
 
 
+@pytest.mark.parametrize("n", [300, 2000, 9000])
+def test_nms_counts_outside_the_batch_are_clamped(va, oracle, n):
+    """counts[i] is held to [0, nmax] inside the kernels: a negative count is an empty image, one beyond nmax the whole row of
+    boxes -- never a read outside the image's boxes (small, mid-size and pruned-path images)."""
+    from vision_amd import ops
+    B = 4
+    boxes = np.zeros((B, n, 4), np.float32); scores = np.zeros((B, n), np.float32)
+    for i in range(B):
+        boxes[i], scores[i] = wl.stress_boxes(40 + i, n, dense=bool(i & 1))
+    counts = np.array([n + 12345, -7, n // 2, 2147483647], np.int32)
+    keep, cnt = ops.nms_batched(torch.from_numpy(boxes).cuda(), torch.from_numpy(scores).cuda(), torch.from_numpy(counts), 0.5, True)
+    keep, cnt = keep.cpu().numpy(), cnt.cpu().numpy()
+    for i, c in enumerate((n, 0, n // 2, n)):
+        want = oracle.nms(boxes[i, :c], scores[i, :c], 0.5, True) if c else np.zeros(0, np.int64)
+        assert cnt[i] == len(want) and np.array_equal(keep[i, :cnt[i]], want), (n, i)
+
+
 @pytest.mark.parametrize("n,dense,thr", [(70001, False, 0.5), (100000, True, 0.6), (270000, True, 0.3)])
 def test_nms_beyond_65536_boxes_vs_oracle(va, oracle, n, dense, thr):
     """Images of more than 65536 boxes: the global bitonic network, the gather, the dense mask and the serial chain over more than

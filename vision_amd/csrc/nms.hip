@@ -61,6 +61,15 @@ struct NmsWs {
     size_t total;
 };
 
+// boxes of image `img`: the caller's count, held to [0, nmax] (a count from outside must not become a read outside the image's
+// boxes), or nmax when there are no counts
+__device__ __forceinline__ int nms_count(const int32_t *__restrict__ counts, int img, int64_t nmax)
+{
+    if (!counts) return (int)nmax;
+    const int c = counts[img];
+    return c < 0 ? 0 : (c > (int)nmax ? (int)nmax : c);
+}
+
 static inline int64_t next_pow2(int64_t v) { int64_t p = 64; while (p < v) p <<= 1; return p; }
 
 static NmsWs nms_layout(int64_t batch, int64_t nmax, void *base)
@@ -132,7 +141,7 @@ __global__ __launch_bounds__(T) void k_nms_sort_small(const float4 *__restrict__
 {
     __shared__ u64 keys[NP2];
     const int img = blockIdx.x, tid = threadIdx.x;
-    const int n = counts ? counts[img] : (int)nmax;
+    const int n = nms_count(counts, img, nmax);
     boxes += (int64_t)img * nmax;
     scores += (int64_t)img * nmax;
     for (int i = tid; i < NP2; i += T) keys[i] = (i < n) ? make_key(scores[i], (u32)i) : ~0ull;
@@ -167,7 +176,7 @@ __global__ __launch_bounds__(256) void k_nms_make_keys(const float *__restrict__
                                                        int64_t nmax, int64_t Np2, u64 *__restrict__ keys)
 {
     const int img = blockIdx.y;
-    const int n = counts ? counts[img] : (int)nmax;
+    const int n = nms_count(counts, img, nmax);
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i < Np2) keys[(int64_t)img * Np2 + i] = (i < n) ? make_key(scores[(int64_t)img * nmax + i], (u32)i) : ~0ull;
 }
@@ -353,7 +362,7 @@ __global__ __launch_bounds__(1024) void k_nms_sort_chunks(const float *__restric
     // reads and conditional writes (15 of them with a barrier) and took 31 us for 64 k keys on its 16 workgroups.
     __shared__ __attribute__((aligned(16))) u64 s[SORT_CHUNK + 8];
     const int tid = threadIdx.x, img = blockIdx.y;
-    const int n = counts ? counts[img] : (int)nmax;
+    const int n = nms_count(counts, img, nmax);
     if ((int64_t)blockIdx.x * SORT_CHUNK >= Np2) {
         // the launch's extra workgroup (pruned path only): the image's x-bucket order, from the caller's boxes (xbucket_image)
         xbucket_image(boxes + (int64_t)img * nmax, n, Np, force, hdr + img, start + (int64_t)img * (XB_G + 1), posu + (int64_t)img * Np,
@@ -426,7 +435,7 @@ __global__ __launch_bounds__(256) void k_nms_merge_rank(const float4 *__restrict
 {
     __shared__ u64 s_max[16][64];                                 // last key of every 64-key block of every chunk
     const int img = blockIdx.y, tid = threadIdx.x;
-    const int n = counts ? counts[img] : (int)nmax;
+    const int n = nms_count(counts, img, nmax);
     const u64 *kimg = keys + (int64_t)img * Np2;
     const int nchunks = (int)(Np2 / SORT_CHUNK);                  // 2 .. 16
     for (int t = tid; t < nchunks * 64; t += 256) s_max[t >> 6][t & 63] = kimg[(int64_t)(t >> 6) * SORT_CHUNK + (t & 63) * 64 + 63];
@@ -508,7 +517,7 @@ __global__ __launch_bounds__(256) void k_nms_gather(const float4 *__restrict__ b
                                                     float *x1, float *y1, float *x2, float *y2, float *area, int32_t *order)
 {
     const int img = blockIdx.y;
-    const int n = counts ? counts[img] : (int)nmax;
+    const int n = nms_count(counts, img, nmax);
     int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= Np) return;                                     // Np is a multiple of 64: whole waves leave
     gather_sorted(boxes + (int64_t)img * nmax, keys[(int64_t)img * Np2 + p], p < n, (int64_t)img * Np + p, x1, y1, x2, y2, area, order);
@@ -552,7 +561,7 @@ __global__ __launch_bounds__(256, 4) void k_nms_mask(const float *__restrict__ s
     __shared__ u64 tile[64][MTW + 1];
     const int img = blockIdx.z;
     if (hdr && hdr[img].mode != 1) return;                    // the pruned path does this image
-    const int n = counts ? counts[img] : (int)nmax;
+    const int n = nms_count(counts, img, nmax);
     const int ib = blockIdx.y;
     const int jt = blockIdx.x, jb0 = jt * MTW;
     if (ib * 64 >= n || (int64_t)jb0 * 64 >= n || jb0 + MTW <= ib) return;   // below the diagonal / outside
@@ -749,7 +758,7 @@ __global__ __launch_bounds__(T) void k_nms_reduce(const u64 *__restrict__ mask, 
                                                   int quirk, int64_t *__restrict__ keep, int32_t *__restrict__ keep_count)
 {
     const int img = blockIdx.x;
-    const int n = counts ? counts[img] : (int)nmax;
+    const int n = nms_count(counts, img, nmax);
     nms_reduce_serial<T, WPT>(mask + (int64_t)img * Np * W, order + (int64_t)img * Np, n, W, quirk, keep + (int64_t)img * nmax,
                               keep_count + img);
 }
@@ -774,7 +783,7 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_small(const u64 *__restric
     __shared__ u64 K[64], R[64], R2[64], Bk[64];
     __shared__ int s_cnt, s_last, s_off[64];
     const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = counts ? counts[img] : (int)nmax;
+    const int n = nms_count(counts, img, nmax);
     const int nb = (n + 63) >> 6;
     mask += (int64_t)img * Np * W;
     rsum += (int64_t)img * Np;                                    // one summary word per row (W <= 64)
@@ -1000,7 +1009,7 @@ __global__ __launch_bounds__(1024) void k_nms_reduce_band(const u64 *__restrict_
     __shared__ int s_nk[2], s_total, s_last_ib, s_last_r;
     __shared__ u64 s_last_curb;
     const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int n = counts ? counts[img] : (int)nmax;
+    const int n = nms_count(counts, img, nmax);
     mask += (int64_t)img * Np * W;
     order += (int64_t)img * Np;
     keep += (int64_t)img * nmax;
@@ -1181,7 +1190,7 @@ __global__ __launch_bounds__(256) void k_nms_csr_count(const u64 *__restrict__ r
 {
     const int img = blockIdx.y;
     if (hdr && hdr[img].mode != 1) return;
-    const int n = counts ? counts[img] : (int)nmax;
+    const int n = nms_count(counts, img, nmax);
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // row; Np is a multiple of 64
     if (i >= Np) return;
     const int ib = (int)(i >> 6);
@@ -1202,7 +1211,7 @@ __global__ __launch_bounds__(1024) void k_nms_csr_scan(const int32_t *__restrict
     __shared__ int64_t sc[1024];
     const int img = blockIdx.x, tid = threadIdx.x;
     if (hdr && hdr[img].mode != 1) return;
-    const int n = counts ? counts[img] : (int)nmax;
+    const int n = nms_count(counts, img, nmax);
     const int nb = (n + 63) >> 6;                                    // <= 1024 here
     const int64_t v = (tid < nb) ? bcnt[(int64_t)img * W + tid] : 0;
     sc[tid] = v;
@@ -1236,7 +1245,7 @@ __global__ __launch_bounds__(256) void k_nms_csr_fill(const u64 *__restrict__ ma
     const int img = blockIdx.y;
     if (hdr && hdr[img].mode != 1) return;
     if (cflag[img] != 1) return;
-    const int n = counts ? counts[img] : (int)nmax;
+    const int n = nms_count(counts, img, nmax);
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t i = t / SW;
     const int s = (int)(t - i * SW);
@@ -1271,7 +1280,7 @@ __global__ __launch_bounds__(256) void k_nms_csr_fill_wave(const u64 *__restrict
     const int img = blockIdx.y;
     if (hdr && hdr[img].mode != 1) return;
     if (!cflag[img]) return;
-    const int n = counts ? counts[img] : (int)nmax;
+    const int n = nms_count(counts, img, nmax);
     const int lane = threadIdx.x & 63;
     const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
     const int64_t i = t >> sw_shift;
@@ -1318,7 +1327,7 @@ __global__ __launch_bounds__(1024) void k_nms_csr_build_small(const u64 *__restr
     __shared__ int s_cnt[64], s_off[65];
     __shared__ int s_fits;
     const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int n = counts ? counts[img] : (int)nmax;
+    const int n = nms_count(counts, img, nmax);
     const int nb = (n + 63) >> 6;                                // <= 64
     u64 bits[4];
     int cnt[4], incl[4];
@@ -1401,7 +1410,7 @@ __global__ __launch_bounds__(1024) void k_nms_reduce_csr(const u64 *__restrict__
         if (hdr && hdr[img].mode != 1) return;                // the pruned path does this image
         if (cflag[img] != 1) return;                          // too dense: k_nms_reduce_band does this image
     }
-    const int n = counts ? counts[img] : (int)nmax;
+    const int n = nms_count(counts, img, nmax);
     mask += (int64_t)img * Np * W;
     if (SEG) diag += (int64_t)img * Np;
     order += (int64_t)img * Np;
@@ -1623,7 +1632,7 @@ __global__ __launch_bounds__(256) void k_nms_estimate(const float4 *__restrict__
     const int img = blockIdx.y;
     NmsHdr *h = hdr + img;
     if (h->mode != 0) return;
-    const int n = counts ? counts[img] : (int)nmax;
+    const int n = nms_count(counts, img, nmax);
     const int64_t o = (int64_t)img * Np;
     const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6);      // 1024 waves per image, one sample each
     u32 sum = 0;
@@ -1685,7 +1694,7 @@ __global__ __launch_bounds__(256, 4) void k_nms_band(const float4 *__restrict__ 
         if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) *(volatile int32_t *)&h->mode = 1;
         return;
     }
-    const int n = counts ? counts[img] : (int)nmax;
+    const int n = nms_count(counts, img, nmax);
     const int t = blockIdx.y;
     if (t * 64 >= n) return;
     const int64_t o = (int64_t)img * Np;
@@ -1930,7 +1939,7 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_mc(NmsHdr *__restrict__ hd
         if (g == 0 && tid == 0) h->npairs = Etot;
         return;
     }
-    const int n = counts ? counts[img] : (int)nmax;
+    const int n = nms_count(counts, img, nmax);
     order += (int64_t)img * Np;
     keep += (int64_t)img * nmax;
     u32 *mcs = mc + (int64_t)img * MC_WORDS;
@@ -2225,7 +2234,7 @@ __global__ __launch_bounds__(1024) void k_nms_resolve_async(NmsHdr *__restrict__
         if (g == 0 && tid == 0) h->npairs = Etot;
         return;
     }
-    const int n = counts ? counts[img] : (int)nmax;
+    const int n = nms_count(counts, img, nmax);
     order += (int64_t)img * Np;
     keep += (int64_t)img * nmax;
     u32 *mcs = mc + (int64_t)img * MC_WORDS;
@@ -2758,7 +2767,7 @@ __global__ __launch_bounds__(1024) void k_nms_class_bin(const float4 *__restrict
     __shared__ int s_base[PC_MAX_CLASSES];
     __shared__ int s_wave[16][PC_MAX_CLASSES];
     const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int n = counts ? counts[img] : (int)nmax;
+    const int n = nms_count(counts, img, nmax);
     boxes += (int64_t)img * nmax;
     scores += (int64_t)img * nmax;
     labels += (int64_t)img * nmax;
