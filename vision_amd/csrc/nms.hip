@@ -19,14 +19,14 @@
 #define SORT_CHUNK 4096  // elements sorted inside LDS (32 KiB of keys)
 #define NMS_CSR_MIN_W 8  // from 8 words (449 boxes) per image on, the reduce runs from the compact mask (k_nms_csr_*)
 
-// per image, 64 bytes: what the pruned path (k_nms_xbucket ...) decided; the dense-mask kernels of an image run iff mode == 1
+// per image, 64 bytes: what the pruned path (xbucket_image ...) decided; the dense-mask kernels of an image run iff mode == 1
 struct NmsHdr {
     float xmin, scale;       // x-bucket of a coordinate: clamp((x - xmin) * scale, 0, XB_G - 1)
     int32_t mode;            // 0: pruned path (banded pair search in x-bucket order); 1: dense mask
     int32_t fpdone;          // k_nms_resolve_mc converged and wrote the keep list
     int32_t rounds;          // rounds it took (diagnostic)
     int32_t npairs;          // suppressing pairs k_nms_band found (all 64 lists; written by k_nms_resolve_mc)
-    int32_t cpb;             // candidate pairs per box, as k_nms_xbucket estimated them
+    int32_t cpb;             // candidate pairs per box, as xbucket_image estimated them
     uint32_t estsum;         // k_nms_estimate: suppressing pairs of 1024 sampled boxes (x n / 1024 = the image's)
     int32_t pad[8];
 };
@@ -2509,7 +2509,7 @@ static int nms_phase_mask(const int32_t *counts, int64_t batch, int64_t nmax, fl
     const bool small = dg_cdiv(w.W, 32) * w.W * batch < 512;
     const NmsHdr *hdr = nullptr;
     if (w.pruned && nms_prune_mode() != 0) {
-        // the pruned pair search for the images k_nms_xbucket chose (hdr.mode == 0); the dense mask below runs for the others
+        // the pruned pair search for the images xbucket_image chose (hdr.mode == 0); the dense mask below runs for the others
         hdr = w.hdr;
         if (standalone) hipLaunchKernelGGL(k_nms_reset_pairs, dim3((unsigned)dg_cdiv(batch * 64, 256)), dim3(256), 0, (hipStream_t)s, w.hdr, w.lcnt, (int)batch);
         if (!fast_ok) {
